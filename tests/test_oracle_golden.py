@@ -1,0 +1,135 @@
+"""The CPU oracle (oracle/moco_bert_oracle.py) against outputs captured from the reference itself
+(tests/golden/*.npz, made by oracle/make_golden.py). fp32, dropout off. Tolerances are fp32
+round-off for a different but algebraically identical op order."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import moco_bert_oracle as O
+from oracle.make_golden import TINY, TINY16, BASE1
+
+ATOL = 2e-5
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def t(x):
+    return torch.from_numpy(np.asarray(x))
+
+
+@pytest.mark.parametrize("name,shape_kw,stride", [
+    ("g1_tiny_encoder.npz", TINY, 1), ("g1b_tiny_d16_encoder.npz", TINY16, 1),
+    ("g2_base_layer_s64.npz", BASE1, 4), ("g2_base_layer_s256.npz", BASE1, 16)])
+def test_encoder_matches_reference(golden_dir, name, shape_kw, stride):
+    g = load(golden_dir, name)
+    cfg = O.BertShape(**shape_kw)
+    P = O.make_params(cfg, int(g["seed"]))
+    chk = np.array([float(sum(v.double().sum() for v in P.values())),
+                    float(sum((v.double() ** 2).sum() for v in P.values()))])
+    np.testing.assert_allclose(chk, g["param_checksum"], rtol=1e-12)
+    ids, mask = t(g["ids"]), t(g["mask"])
+    with torch.no_grad():
+        for pooling in ("average", "cls"):
+            for norm in (0, 1):
+                emb, hidden = O.encoder_forward(P, ids, mask, cfg, pooling, bool(norm), return_hidden=True)
+                ref = t(g[f"emb_{pooling}_{norm}"])
+                assert torch.allclose(emb, ref, atol=ATOL, rtol=1e-4), (pooling, norm, (emb - ref).abs().max())
+        hid = torch.stack(hidden)[:, :, ::stride]
+        assert torch.allclose(hid, t(g["hidden"]), atol=5e-5, rtol=1e-4), (hid - t(g["hidden"])).abs().max()
+
+
+def test_encoder_grads_match_reference(golden_dir):
+    g = load(golden_dir, "g7_tiny_grads.npz")
+    cfg = O.BertShape(**TINY)
+    ids, mask, cot = t(g["ids"]), t(g["mask"]), t(g["cot"])
+    for pooling, norm in (("average", False), ("average", True), ("cls", False)):
+        P = {n: v.requires_grad_(True) for n, v in O.make_params(cfg, int(g["seed"])).items()}
+        emb = O.encoder_forward(P, ids, mask, cfg, pooling, norm)
+        (emb * cot).sum().backward()
+        tag = f"{pooling}_{int(norm)}"
+        for n, p in P.items():
+            ref = t(g[f"grad_{tag}::{n}"])
+            scale = max(1e-6, float(ref.abs().max()))
+            assert float((p.grad - ref).abs().max()) <= 2e-4 * scale + 1e-6, (tag, n)
+
+
+def test_head_matches_reference(golden_dir):
+    g = load(golden_dir, "g3_head.npz")
+    q, k = t(g["q"]), t(g["k"])
+    queue = torch.nn.functional.normalize(O.det_uniform((768, 512), int(g["queue_seed"])), dim=0) * 2.0
+    for T, ls in ((0.05, 0.0), (0.05, 0.1), (1.0, 0.0)):
+        tag = f"T{T}_ls{ls}"
+        qq = q.clone().requires_grad_(True)
+        loss, logits = O.infonce_loss(qq, k, queue, T, ls)
+        loss.backward()
+        assert torch.allclose(logits, t(g[f"logits_{tag}"]), atol=1e-3, rtol=1e-5)
+        assert abs(float(loss) - float(g[f"loss_{tag}"])) < 1e-4
+        assert torch.allclose(qq.grad, t(g[f"dq_{tag}"]), atol=1e-5, rtol=1e-4)
+        acc, stdq, stdk = O.step_stats(logits.detach(), q, k)
+        assert float(acc) == float(g[f"acc_{tag}"])
+    assert abs(float(stdq) - float(g["stdq"])) < 1e-6 and abs(float(stdk) - float(g["stdk"])) < 1e-6
+
+
+def test_ema_matches_reference(golden_dir):
+    g = load(golden_dir, "g4_ema.npz")
+    cfg = O.BertShape(**TINY)
+    Pq, Pk = O.make_params(cfg, 41), O.make_params(cfg, 42)
+    for step in range(3):
+        for i, n in enumerate(Pq):
+            Pq[n] = Pq[n] + O.det_uniform(tuple(Pq[n].shape), 4300 + 100 * step + i, -1e-2, 1e-2)
+        Pk = O.ema_update(Pk, Pq, 0.9995)
+        flat = torch.cat([Pk[n].reshape(-1) for n, _ in O.param_names(cfg)])
+        assert torch.equal(flat[::97], t(g[f"k_flat_step{step}"]))
+
+
+def test_enqueue_matches_reference(golden_dir):
+    g = load(golden_dir, "g5_enqueue.npz")
+    C, K, n = 32, 512, 64
+    queue = torch.nn.functional.normalize(O.det_uniform((C, K), 51), dim=0)
+    ptr = 0
+    for step in range(10):
+        queue, ptr = O.enqueue(queue, ptr, O.det_uniform((n, C), 5200 + step))
+        assert ptr == int(g["ptrs"][step])
+        assert abs(float(queue.double().sum()) - float(g["sums"][step])) < 1e-9
+    assert torch.equal(queue, t(g["queue_final"]))
+
+
+def test_adamw_and_schedule_match_reference(golden_dir):
+    g = load(golden_dir, "g6_adamw.npz")
+    for warm in (-1, 0, 3):
+        lam = [O.warmup_linear(s, warm, 10, 0.1) for s in range(12)]
+        np.testing.assert_allclose(lam, g[f"lambda_w{warm}"], rtol=1e-12, atol=0)
+        p = O.det_uniform((1000,), 61)
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        for step in range(5):
+            lr = 1e-2 * O.warmup_linear(step, warm, 10, 0.1)
+            assert abs(lr - float(g[f"lrs_w{warm}"][step])) < 1e-15
+            grad = O.det_uniform((1000,), 6200 + step, -0.5, 0.5)
+            p, m, v = O.adamw_step(p, grad, m, v, step + 1, lr, 0.9, 0.98, 1e-6, 0.01)
+            assert torch.allclose(p, t(g[f"p_w{warm}"][step]), atol=2e-7, rtol=1e-6)
+
+
+def test_moco_trace_matches_reference(golden_dir):
+    from oracle.make_golden import ragged_batch
+    g = load(golden_dir, "g8_moco_trace.npz")
+    cfg = O.BertShape(**TINY)
+    P = O.make_params(cfg, 71)
+    queue = torch.nn.functional.normalize(O.det_uniform((cfg.hidden_size, 64), 72), dim=0)
+    st = O.MoCoState(cfg, P, queue, momentum=0.99, temperature=0.05)
+    B, S = 8, 24
+    for step in range(5):
+        q_tokens, q_mask = ragged_batch(B, S, 7300 + step, cfg.vocab_size, [S, 17, 3, 24, 9, 24, 12, 20])
+        k_tokens, k_mask = ragged_batch(B, S, 7400 + step, cfg.vocab_size, [20, S, 5, 11, 24, 7, 24, 16])
+        loss, q, k, stats = st.forward_backward(q_tokens, q_mask, k_tokens, k_mask)
+        st.optimizer_step(1e-3 * O.warmup_linear(step, 2, 10, 0.0))
+        assert abs(float(loss) - float(g["losses"][step])) < 2e-4, (step, float(loss), float(g["losses"][step]))
+        assert float(stats["accuracy"]) == float(g["accs"][step])
+        assert st.ptr == int(g["ptrs"][step])
+        assert torch.allclose(q, t(g["q"][step]), atol=1e-4)
+    assert torch.allclose(st.queue, t(g["queue_final"]), atol=1e-4)
+    assert torch.allclose(st.Pq["encoder.layer.1.output.dense.weight"].detach()[::7, ::5], t(g["wq_probe"]), atol=1e-5)
+    assert torch.allclose(st.Pk["encoder.layer.1.output.dense.weight"][::7, ::5], t(g["wk_probe"]), atol=1e-6)
