@@ -1,0 +1,68 @@
+"""Builds libczc.so (the gfx950 kernels + C ABI) in-tree with hipcc.  No GPU needed: hipcc cross-compiles."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libczc.so")
+SOURCES = ["api.cpp", "gemm_bf16.hip", "attention.hip", "rowops.hip", "head.hip", "optim.hip", "encoder.hip"]
+HEADERS = ["czc_common.h", "gemm_args.h", os.path.join("..", "..", "include", "czc.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libczc.so cannot be built")
+    return exe
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    jobs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+        if force or _stale(op, [sp] + hdrs):
+            jobs.append((sp, op))
+
+    def compile_one(job):
+        sp, op = job
+        cmd = [_hipcc()] + FLAGS + (["-x", "hip"] if sp.endswith(".cpp") else []) + ["-c", sp, "-o", op]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {sp}:\n{r.stdout}\n{r.stderr}")
+        return sp
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            for sp in ex.map(compile_one, jobs):
+                if verbose:
+                    print(f"[czc build] compiled {os.path.basename(sp)}", file=sys.stderr)
+    objs = [os.path.join(OBJ, os.path.splitext(s)[0] + ".o") for s in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"[czc build] linked {LIB}", file=sys.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,440 @@
+// attention.hip — BERT self-attention (head_dim 64, key-padding mask, prob-dropout) for gfx950.
+//
+// Replaces HF BertSelfAttention's softmax(QK^T/8 + mask) V and its autograd backward
+// (HF modeling_bert.py eager_attention_forward; call site src/contriever.py:32-43).
+// Layout: qkv bf16 [B*S, 3H] straight out of the fused QKV GEMM (Q | K | V, head h at columns
+// 64h), ctx bf16 [B*S, H] straight into the output-projection GEMM: no head transposes in HBM.
+//
+// All three kernels are "query/key on the lane": with v_mfma_f32_32x32x16_bf16 the score tile is
+// produced TRANSPOSED so that its softmax statistics (running max / sum, lse, delta) live in the
+// lane that owns the column, never in another lane, and the bf16 probabilities are fed to the
+// second product directly from the accumulator registers (no LDS round trip):
+//   forward   S^T = K Q^T  (key rows x query cols)  ->  O^T += V^T P^T        per 64-key block
+//   dQ kernel S^T, dP^T = V dO^T                     ->  dQ^T += K^T dS^T
+//   dKdV      S = Q K^T, dP = dO V^T (query rows x key cols) -> dV^T += dO^T P~, dK^T += Q^T dS
+// K/V (or Q/dO) blocks are staged in LDS as [rows][64] bf16 with 16-B chunks XOR-swizzled by
+// swz64(row) so that both the ds_read_b128 row reads and the ds_read_b64_tr_b16 column reads are
+// bank-conflict free.  The backward is two kernels (5+... products recomputing S twice) rather than
+// one with a cross-wave / atomic dQ reduction: 0.8 % more FLOPs of the step, bitwise reproducible.
+#include "czc_common.h"
+
+namespace czc {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float NEG_MASK = -2.0e30f;  // masked score (log2 domain); running max starts at -1e30
+
+__device__ __forceinline__ int swz64(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+
+// stage ROWS x 64 bf16 (rows `row0..`, zero beyond nvalid) into a swizzled LDS tile
+template <int ROWS>
+__device__ __forceinline__ void load_tile(const bf16_t* __restrict__ src, int ld, int nvalid, unsigned char* lds, int tid) {
+#pragma unroll
+  for (int id = tid; id < ROWS * 8; id += 256) {
+    const int row = id >> 3, c = id & 7;
+    uint4 v = {0u, 0u, 0u, 0u};
+    if (row < nvalid) v = *(const uint4*)(src + (size_t)row * ld + c * 8);
+    *(uint4*)(lds + row * 128 + ((c ^ swz64(row)) << 4)) = v;
+  }
+}
+// 32x32x16 A/B operand by rows: lane (r = lane&31, h = lane>>5) holds tile[row0 + r][16ks + 8h .. +7]
+__device__ __forceinline__ bf16x8 frag_row(const unsigned char* lds, int row0, int ks, int lane) {
+  const int row = row0 + (lane & 31), c = 2 * ks + (lane >> 5);
+  return *(const bf16x8*)(lds + row * 128 + ((c ^ swz64(row)) << 4));
+}
+// 32x32x16 operand by columns (transposing read), in the k-order of an accumulator-fed partner:
+// lane (r, h) element j = tile[rbase + 8(j>>2) + 4h + (j&3)][col0 + r]      (rbase multiple of 16)
+__device__ __forceinline__ bf16x8 frag_tr(const unsigned char* lds, int rbase, int col0, int lane) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3, h = g >> 1;
+  const int c = (col0 >> 3) + 2 * (g & 1) + (p >> 1);
+  const int row1 = rbase + 4 * h + q, row2 = row1 + 8;
+  typedef s16x4 __attribute__((address_space(3)))* trp_t;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(lds + row1 * 128 + ((c ^ swz64(row1)) << 4) + 8 * (p & 1)));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(lds + row2 * 128 + ((c ^ swz64(row2)) << 4) + 8 * (p & 1)));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+// registers 8s .. 8s+7 of an accumulator tile as the bf16 operand of k-step s
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s) {
+  bf16x8 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (__bf16)a[8 * s + j];
+  return f;
+}
+__device__ __forceinline__ bf16x8 ld_frag_global(const bf16_t* p) {
+  const uint4 v = *(const uint4*)p;
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ float keep16(uint32_t r, int odd, uint32_t thr, float inv_keep) {
+  const uint32_t d = odd ? (r >> 16) : (r & 0xffffu);
+  return d >= thr ? inv_keep : 0.f;
+}
+
+struct AttnArgs {
+  const bf16_t* qkv; const uint8_t* mask; const bf16_t* ctx; const bf16_t* dctx;
+  const float* lse_in; float* lse; float* delta; bf16_t* out; bf16_t* dqkv;
+  int B, S, nh, H;
+  uint32_t thr, seed, site;
+  float inv_keep;
+};
+
+// key-padding bias (log2 domain) for the whole (padded) sequence
+__device__ __forceinline__ void load_mask_bias(const AttnArgs& a, int b, float* mb, int spad, int tid) {
+  for (int s = tid; s < spad; s += 256) mb[s] = (s < a.S && a.mask[(size_t)b * a.S + s]) ? 0.f : NEG_MASK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+template <bool DROP>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char kt[64 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char vt[64 * 128];
+  __shared__ __attribute__((aligned(16))) float mb[512];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, hh = blockIdx.y;
+  const int S = a.S, H3 = 3 * a.H;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int r = lane & 31, h = lane >> 5;
+  const int spad = (S + 63) & ~63;
+  const bool active = q0 < S;  // wave-uniform
+  const float c2 = 0.125f * LOG2E;
+
+  load_mask_bias(a, b, mb, spad, tid);
+
+  const bf16_t* base = a.qkv + (size_t)b * S * H3 + hh * 64;
+  bf16x8 bq[4];
+  {
+    int qr = q0 + r; if (qr > S - 1) qr = S - 1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) bq[ks] = ld_frag_global(base + (size_t)qr * H3 + 16 * ks + 8 * h);
+  }
+  f32x16 o[2];
+  o[0] = o[1] = (f32x16)(0.f);
+  float m = -1.0e30f, l = 0.f;
+  const uint32_t erow = DROP ? ((uint32_t)((b * a.nh + hh) * S + (q0 + r)) * (uint32_t)S) : 0u;
+
+  for (int kb0 = 0; kb0 < S; kb0 += 64) {
+    __syncthreads();
+    load_tile<64>(base + a.H + (size_t)kb0 * H3, H3, S - kb0, kt, tid);
+    load_tile<64>(base + 2 * a.H + (size_t)kb0 * H3, H3, S - kb0, vt, tid);
+    __syncthreads();
+    if (!active) continue;
+    f32x16 s[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      s[tt] = (f32x16)(0.f);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        s[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(kt, 32 * tt, ks, lane), bq[ks], s[tt], 0, 0, 0);
+    }
+    float mx = m;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bias = *(const f32x4*)(mb + kb0 + 32 * tt + 8 * g + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float x = s[tt][4 * g + j] * c2 + bias[j];
+          s[tt][4 * g + j] = x;
+          mx = fmaxf(mx, x);
+        }
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float alpha = __builtin_amdgcn_exp2f(m - mx);
+    m = mx;
+    float ps = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float p = __builtin_amdgcn_exp2f(s[tt][i] - mx);
+        s[tt][i] = p;
+        ps += p;
+      }
+    l = l * alpha + ps;
+    o[0] *= alpha;
+    o[1] *= alpha;
+    if (DROP) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const uint32_t e = erow + (uint32_t)(kb0 + 32 * tt + 8 * g + 4 * h);
+          const uint32_t r0 = czc_rng_pair(a.seed, a.site, e >> 1), r1 = czc_rng_pair(a.seed, a.site, (e >> 1) + 1);
+          s[tt][4 * g + 0] *= keep16(r0, 0, a.thr, a.inv_keep);
+          s[tt][4 * g + 1] *= keep16(r0, 1, a.thr, a.inv_keep);
+          s[tt][4 * g + 2] *= keep16(r1, 0, a.thr, a.inv_keep);
+          s[tt][4 * g + 3] *= keep16(r1, 1, a.thr, a.inv_keep);
+        }
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = acc_frag(s[tt], s2);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 32 * tt + 16 * s2, 32 * dt, lane), pf, o[dt], 0, 0, 0);
+      }
+  }
+  if (!active) return;
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+  const int q = q0 + r;
+  if (q < S) {
+    bf16_t* dst = a.out + ((size_t)b * S + q) * a.H + hh * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 w;
+        w.x = pack2bf(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv);
+        w.y = pack2bf(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        *(uint2*)(dst + 32 * dt + 8 * g + 4 * h) = w;
+      }
+    if (h == 0) a.lse[((size_t)b * a.nh + hh) * S + q] = (m + __log2f(l)) * LN2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward 1: dQ (and delta = rowsum(dO * O)).  One wave = 32 queries, sweeps 64-key blocks.
+// ---------------------------------------------------------------------------------------------
+template <bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char kt[64 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char vt[64 * 128];
+  __shared__ __attribute__((aligned(16))) float mb[512];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, hh = blockIdx.y;
+  const int S = a.S, H3 = 3 * a.H;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int r = lane & 31, h = lane >> 5;
+  const int spad = (S + 63) & ~63;
+  const bool active = q0 < S;
+  const float c2 = 0.125f * LOG2E;
+
+  load_mask_bias(a, b, mb, spad, tid);
+
+  const bf16_t* base = a.qkv + (size_t)b * S * H3 + hh * 64;
+  int qr = q0 + r; if (qr > S - 1) qr = S - 1;
+  const bool qvalid = (q0 + r) < S;
+  bf16x8 bq[4], bdo[4];
+  float dl = 0.f;
+  {
+    const bf16_t* dop = a.dctx + ((size_t)b * S + qr) * a.H + hh * 64;
+    const bf16_t* op = a.ctx + ((size_t)b * S + qr) * a.H + hh * 64;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bq[ks] = ld_frag_global(base + (size_t)qr * H3 + 16 * ks + 8 * h);
+      bdo[ks] = ld_frag_global(dop + 16 * ks + 8 * h);
+      const bf16x8 of = ld_frag_global(op + 16 * ks + 8 * h);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dl += (float)bdo[ks][j] * (float)of[j];
+    }
+  }
+  dl += __shfl_xor(dl, 32, 64);
+  const float lse2 = qvalid ? a.lse_in[((size_t)b * a.nh + hh) * S + qr] * LOG2E : 1.0e30f;
+  if (active && qvalid && h == 0) a.delta[((size_t)b * a.nh + hh) * S + qr] = dl;
+
+  f32x16 dq[2];
+  dq[0] = dq[1] = (f32x16)(0.f);
+  const uint32_t erow = DROP ? ((uint32_t)((b * a.nh + hh) * S + (q0 + r)) * (uint32_t)S) : 0u;
+
+  for (int kb0 = 0; kb0 < S; kb0 += 64) {
+    __syncthreads();
+    load_tile<64>(base + a.H + (size_t)kb0 * H3, H3, S - kb0, kt, tid);
+    load_tile<64>(base + 2 * a.H + (size_t)kb0 * H3, H3, S - kb0, vt, tid);
+    __syncthreads();
+    if (!active) continue;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      f32x16 s = (f32x16)(0.f), dp = (f32x16)(0.f);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(kt, 32 * tt, ks, lane), bq[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(vt, 32 * tt, ks, lane), bdo[ks], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bias = *(const f32x4*)(mb + kb0 + 32 * tt + 8 * g + 4 * h);
+        float z[4] = {1.f, 1.f, 1.f, 1.f};
+        if (DROP) {
+          const uint32_t e = erow + (uint32_t)(kb0 + 32 * tt + 8 * g + 4 * h);
+          const uint32_t r0 = czc_rng_pair(a.seed, a.site, e >> 1), r1 = czc_rng_pair(a.seed, a.site, (e >> 1) + 1);
+          z[0] = keep16(r0, 0, a.thr, a.inv_keep); z[1] = keep16(r0, 1, a.thr, a.inv_keep);
+          z[2] = keep16(r1, 0, a.thr, a.inv_keep); z[3] = keep16(r1, 1, a.thr, a.inv_keep);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float p = __builtin_amdgcn_exp2f(s[4 * g + j] * c2 + bias[j] - lse2);
+          s[4 * g + j] = p * (z[j] * dp[4 * g + j] - dl);   // dS^T (before the 1/8 scale)
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 df = acc_frag(s, s2);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 32 * tt + 16 * s2, 32 * dt, lane), df, dq[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (!active || !qvalid) return;
+  bf16_t* dst = a.dqkv + ((size_t)b * S + q0 + r) * H3 + hh * 64;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      uint2 w;
+      w.x = pack2bf(dq[dt][4 * g] * 0.125f, dq[dt][4 * g + 1] * 0.125f);
+      w.y = pack2bf(dq[dt][4 * g + 2] * 0.125f, dq[dt][4 * g + 3] * 0.125f);
+      *(uint2*)(dst + 32 * dt + 8 * g + 4 * h) = w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward 2: dK, dV.  One wave = 32 keys, sweeps 32-query blocks (Q, dO, lse, delta in LDS).
+// ---------------------------------------------------------------------------------------------
+template <bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char qt[32 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char dot[32 * 128];
+  __shared__ __attribute__((aligned(16))) float lse_s[32];
+  __shared__ __attribute__((aligned(16))) float del_s[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, hh = blockIdx.y;
+  const int S = a.S, H3 = 3 * a.H;
+  const int k0 = blockIdx.x * 128 + wave * 32;
+  const int r = lane & 31, h = lane >> 5;
+  const bool active = k0 < S;
+  const float c2 = 0.125f * LOG2E;
+
+  const bf16_t* base = a.qkv + (size_t)b * S * H3 + hh * 64;
+  int kr = k0 + r; if (kr > S - 1) kr = S - 1;
+  const bool kvalid = (k0 + r) < S;
+  const float kbias = (kvalid && a.mask[(size_t)b * S + kr]) ? 0.f : NEG_MASK;
+  bf16x8 bk[4], bv[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    bk[ks] = ld_frag_global(base + a.H + (size_t)kr * H3 + 16 * ks + 8 * h);
+    bv[ks] = ld_frag_global(base + 2 * a.H + (size_t)kr * H3 + 16 * ks + 8 * h);
+  }
+  f32x16 dk[2], dv[2];
+  dk[0] = dk[1] = dv[0] = dv[1] = (f32x16)(0.f);
+  const uint32_t ebase = (uint32_t)((b * a.nh + hh) * S) * (uint32_t)S + (uint32_t)(k0 + r);
+
+  for (int qb0 = 0; qb0 < S; qb0 += 32) {
+    __syncthreads();
+    load_tile<32>(base + (size_t)qb0 * H3, H3, S - qb0, qt, tid);
+    load_tile<32>(a.dctx + ((size_t)b * S + qb0) * a.H + hh * 64, a.H, S - qb0, dot, tid);
+    if (tid < 32) {
+      const int q = qb0 + tid;
+      lse_s[tid] = (q < S) ? a.lse_in[((size_t)b * a.nh + hh) * S + q] * LOG2E : 1.0e30f;
+      del_s[tid] = (q < S) ? a.delta[((size_t)b * a.nh + hh) * S + q] : 0.f;
+    }
+    __syncthreads();
+    if (!active) continue;
+    f32x16 s = (f32x16)(0.f), dp = (f32x16)(0.f);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(qt, 0, ks, lane), bk[ks], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(dot, 0, ks, lane), bv[ks], dp, 0, 0, 0);
+    }
+    // rows (registers) are queries 8g + 4h + j, the lane is the key
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 l4 = *(const f32x4*)(lse_s + 8 * g + 4 * h);
+      const f32x4 d4 = *(const f32x4*)(del_s + 8 * g + 4 * h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float p = __builtin_amdgcn_exp2f(s[4 * g + j] * c2 + kbias - l4[j]);
+        float z = 1.f;
+        if (DROP) {
+          const uint32_t e = ebase + (uint32_t)(qb0 + 8 * g + 4 * h + j) * (uint32_t)S;
+          z = keep16(czc_rng_pair(a.seed, a.site, e >> 1), (int)(e & 1u), a.thr, a.inv_keep);
+        }
+        const float dpz = z * dp[4 * g + j];
+        dp[4 * g + j] = p * (dpz - d4[j]);  // dS
+        s[4 * g + j] = p * z;               // P~
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16x8 pf = acc_frag(s, s2), df = acc_frag(dp, s2);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot, 16 * s2, 32 * dt, lane), pf, dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 16 * s2, 32 * dt, lane), df, dk[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (!active || !kvalid) return;
+  bf16_t* dstk = a.dqkv + ((size_t)b * S + k0 + r) * H3 + a.H + hh * 64;
+  bf16_t* dstv = dstk + a.H;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      uint2 w;
+      w.x = pack2bf(dk[dt][4 * g] * 0.125f, dk[dt][4 * g + 1] * 0.125f);
+      w.y = pack2bf(dk[dt][4 * g + 2] * 0.125f, dk[dt][4 * g + 3] * 0.125f);
+      *(uint2*)(dstk + 32 * dt + 8 * g + 4 * h) = w;
+      w.x = pack2bf(dv[dt][4 * g], dv[dt][4 * g + 1]);
+      w.y = pack2bf(dv[dt][4 * g + 2], dv[dt][4 * g + 3]);
+      *(uint2*)(dstv + 32 * dt + 8 * g + 4 * h) = w;
+    }
+}
+
+static int attn_check(const char* who, int B, int S, int nh, float p) {
+  CZC_REQUIRE(B > 0 && S > 0 && S <= 512 && nh > 0, "%s: batch=%d seq=%d heads=%d (seq <= 512)", who, B, S, nh);
+  CZC_REQUIRE(p >= 0.f && p < 1.f, "%s: dropout_p=%f", who, p);
+  CZC_REQUIRE((uint64_t)B * nh * S * S < (1ull << 32), "%s: batch*heads*seq*seq must be < 2^32 (dropout counter)", who);
+  return CZC_OK;
+}
+
+}  // namespace czc
+
+using namespace czc;
+
+extern "C" int czc_attention_forward(const uint16_t* qkv, const uint8_t* mask, int batch, int seq, int heads,
+                                     float dropout_p, uint32_t seed, uint32_t site, uint16_t* ctx, float* lse,
+                                     czc_stream_t stream) {
+  if (int rc = attn_check("czc_attention_forward", batch, seq, heads, dropout_p)) return rc;
+  AttnArgs a{};
+  a.qkv = qkv; a.mask = mask; a.out = ctx; a.lse = lse;
+  a.B = batch; a.S = seq; a.nh = heads; a.H = heads * 64;
+  a.thr = dropout_p > 0.f ? czc_drop_thr(dropout_p) : 0u;
+  a.inv_keep = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f;
+  a.seed = seed; a.site = site;
+  dim3 grid(ceil_div(seq, 128), heads, batch);
+  if (a.thr) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
+extern "C" int czc_attention_backward(const uint16_t* qkv, const uint8_t* mask, const uint16_t* ctx,
+                                      const uint16_t* dctx, const float* lse, int batch, int seq, int heads,
+                                      float dropout_p, uint32_t seed, uint32_t site, float* delta, uint16_t* dqkv,
+                                      czc_stream_t stream) {
+  if (int rc = attn_check("czc_attention_backward", batch, seq, heads, dropout_p)) return rc;
+  AttnArgs a{};
+  a.qkv = qkv; a.mask = mask; a.ctx = ctx; a.dctx = dctx; a.lse_in = lse; a.delta = delta; a.dqkv = dqkv;
+  a.B = batch; a.S = seq; a.nh = heads; a.H = heads * 64;
+  a.thr = dropout_p > 0.f ? czc_drop_thr(dropout_p) : 0u;
+  a.inv_keep = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f;
+  a.seed = seed; a.site = site;
+  dim3 grid(ceil_div(seq, 128), heads, batch);
+  hipStream_t st = (hipStream_t)stream;
+  if (a.thr) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, grid, dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, grid, dim3(256), 0, st, a);
+  }
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}

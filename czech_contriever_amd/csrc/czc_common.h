@@ -1,0 +1,102 @@
+// czc_common.h — shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels.
+// wave = 64 lanes everywhere in this tree.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/czc.h"
+
+namespace czc {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef unsigned short bf16_t;  // storage type for bf16 in global memory
+
+// ---- error plumbing (host) -----------------------------------------------------------
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define CZC_HIP(expr)                                                     \
+  do {                                                                    \
+    hipError_t _e = (expr);                                               \
+    if (_e != hipSuccess) return czc::hip_fail(_e, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+#define CZC_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      czc::set_error(__VA_ARGS__);        \
+      return CZC_ERR_INVALID;             \
+    }                                     \
+  } while (0)
+
+#define CZC_LAUNCH_CHECK() CZC_HIP(hipGetLastError())
+
+// ---- bf16 <-> f32 --------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  // plain cast keeps NaN a NaN and lowers to v_cvt_pk_bf16_f32 (round-to-nearest-even)
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// ---- wave (64-lane) reductions ----------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- counter-based dropout RNG -------------------------------------------------------
+// One 32-bit hash gives two 16-bit uniform draws.  keep <=> draw >= thr, thr = round(p*65536).
+// The same function is restated in numpy by tests/dropout_ref.py so that the oracle can be
+// given identical masks.
+__host__ __device__ __forceinline__ uint32_t czc_hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+__host__ __device__ __forceinline__ uint32_t czc_rng_pair(uint32_t seed, uint32_t site, uint32_t pair_index) {
+  return czc_hash32(pair_index ^ czc_hash32(seed + 0x9E3779B9u * (site + 1u)));
+}
+// keep-flag of element e (pairs are (2i, 2i+1))
+__host__ __device__ __forceinline__ bool czc_keep(uint32_t seed, uint32_t site, uint32_t e, uint32_t thr) {
+  uint32_t r = czc_rng_pair(seed, site, e >> 1);
+  uint32_t d = (e & 1u) ? (r >> 16) : (r & 0xffffu);
+  return d >= thr;
+}
+__host__ __device__ __forceinline__ uint32_t czc_drop_thr(float p) {
+  return (uint32_t)(p * 65536.0f + 0.5f);
+}
+
+// exact erf-GELU and its derivative (HF "gelu")
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// 16 bytes of zeros in global memory: out-of-range 16-B chunks of GEMM / attention operands are
+// redirected here (a per-lane source address costs nothing with global_load_lds).
+static __device__ uint4 g_zero16[4];
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace czc

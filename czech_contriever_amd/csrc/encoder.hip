@@ -1,0 +1,276 @@
+// encoder.hip — host-side orchestration of the BERT encoder forward / backward on one stream.
+//
+// Replaces Contriever.forward (src/contriever.py:17-55, i.e. HF BertModel.forward + pooling) and
+// the autograd backward that train.py:264 triggers, as two C calls.  No allocation, no
+// synchronisation: every kernel below is enqueued on the caller's stream, activations live in a
+// caller-provided workspace laid out by enc_layout().
+//
+// Per layer, forward:   qkv = x Wqkv^T + b          (one fused [3H,H] GEMM, bias epilogue)
+//                        ctx = attention(qkv)        (flash-style, attention.hip)
+//                        y1  = ctx Wo^T + b ; x1 = LN(drop(y1) + x)
+//                        u,h = x1 W1^T + b, gelu(u)  (GELU fused in the GEMM epilogue)
+//                        y2  = h W2^T + b  ; x'  = LN(drop(y2) + x1)
+// Backward mirrors it; weight gradients are [N',K'] = dY^T X GEMMs whose operands are both read
+// through transposing LDS reads, split over the token dimension into fp32 slabs.
+#include "czc_common.h"
+#include "gemm_args.h"
+
+namespace czc {
+
+static inline int64_t al256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+struct ParamLayout {
+  int64_t LA, LB, regionA, regionB, total;
+  int64_t H, I, L, V, P, T;
+};
+static ParamLayout param_layout(const czc_bert_shape* s) {
+  ParamLayout p;
+  p.H = s->hidden_size; p.I = s->intermediate_size; p.L = s->num_layers;
+  p.V = s->vocab_size; p.P = s->max_position; p.T = s->type_vocab_size;
+  p.LA = 4 * p.H * p.H + 2 * p.I * p.H;
+  p.LB = 9 * p.H + p.I;
+  p.regionA = p.L * p.LA;
+  p.regionB = p.L * p.LB;
+  p.total = p.regionA + p.regionB + (p.V + p.P + p.T + 2) * p.H;
+  return p;
+}
+static int64_t param_off(const ParamLayout& p, int kind, int l) {
+  const int64_t H = p.H, I = p.I;
+  const int64_t a = l * p.LA, b = p.regionA + l * p.LB, c = p.regionA + p.regionB;
+  switch (kind) {
+    case CZC_P_WQKV: return a;
+    case CZC_P_WO: return a + 3 * H * H;
+    case CZC_P_W1: return a + 4 * H * H;
+    case CZC_P_W2: return a + 4 * H * H + I * H;
+    case CZC_P_BQKV: return b;
+    case CZC_P_BO: return b + 3 * H;
+    case CZC_P_LN1W: return b + 4 * H;
+    case CZC_P_LN1B: return b + 5 * H;
+    case CZC_P_B1: return b + 6 * H;
+    case CZC_P_B2: return b + 6 * H + I;
+    case CZC_P_LN2W: return b + 7 * H + I;
+    case CZC_P_LN2B: return b + 8 * H + I;
+    case CZC_P_WORD: return c;
+    case CZC_P_POS: return c + p.V * H;
+    case CZC_P_TYPE: return c + (p.V + p.P) * H;
+    case CZC_P_ELNW: return c + (p.V + p.P + p.T) * H;
+    case CZC_P_ELNB: return c + (p.V + p.P + p.T + 1) * H;
+  }
+  return -1;
+}
+
+static int shape_check(const char* who, const czc_bert_shape* s) {
+  CZC_REQUIRE(s, "%s: null shape", who);
+  CZC_REQUIRE(s->hidden_size > 0 && s->hidden_size % 64 == 0 && s->hidden_size <= 1024,
+              "%s: hidden_size=%d must be a multiple of 64 and <= 1024", who, s->hidden_size);
+  CZC_REQUIRE(s->num_heads > 0 && s->hidden_size == s->num_heads * 64,
+              "%s: only head_dim 64 is built (hidden_size=%d, num_heads=%d)", who, s->hidden_size, s->num_heads);
+  CZC_REQUIRE(s->intermediate_size > 0 && s->intermediate_size % 64 == 0, "%s: intermediate_size=%d must be a multiple of 64", who, s->intermediate_size);
+  CZC_REQUIRE(s->num_layers > 0 && s->vocab_size > 0 && s->max_position > 0 && s->type_vocab_size > 0, "%s: bad shape", who);
+  return CZC_OK;
+}
+
+struct LayerWs { int64_t qkv, ctx, lse, y1, st1, x1, u, hact, y2, st2; };
+struct EncLayout {
+  int64_t x[64 + 1];
+  LayerWs layer[64];
+  int64_t st0, raw, total;
+};
+static EncLayout enc_layout(const czc_bert_shape* s, int B, int S, int save) {
+  EncLayout e;
+  const int64_t M = (int64_t)B * S, H = s->hidden_size, I = s->intermediate_size, L = s->num_layers;
+  int64_t o = 0;
+  auto take = [&](int64_t bytes) { int64_t r = o; o += al256(bytes); return r; };
+  e.st0 = take(M * 2 * 4);
+  e.raw = take((int64_t)B * H * 4);
+  if (save) {
+    for (int l = 0; l <= L; ++l) e.x[l] = take(M * H * 2);
+  } else {
+    const int64_t x0 = take(M * H * 2), x1 = take(M * H * 2);
+    for (int l = 0; l <= L; ++l) e.x[l] = (l & 1) ? x1 : x0;
+  }
+  for (int l = 0; l < L; ++l) {
+    if (save || l == 0) {
+      LayerWs& w = e.layer[l];
+      w.qkv = take(M * 3 * H * 2); w.ctx = take(M * H * 2); w.lse = take((int64_t)B * s->num_heads * S * 4);
+      w.y1 = take(M * H * 2); w.st1 = take(M * 2 * 4); w.x1 = take(M * H * 2);
+      w.u = take(M * I * 2); w.hact = take(M * I * 2); w.y2 = take(M * H * 2); w.st2 = take(M * 2 * 4);
+    } else {
+      e.layer[l] = e.layer[0];
+    }
+  }
+  e.total = o;
+  return e;
+}
+
+struct BwdLayout { int64_t g0, z, y, x1, c, q3, u, delta, slabs, total; int64_t slab_bytes; };
+static int dw_splits(int Mo, int No, int64_t Kred) {
+  const int tiles = ceil_div(Mo, 256) * ceil_div(No, 256);
+  int sp = 256 / tiles;
+  if (sp < 1) sp = 1;
+  const int kt = (int)ceil_div64(Kred, 64);
+  if (sp > kt) sp = kt;
+  return sp;
+}
+static BwdLayout bwd_layout(const czc_bert_shape* s, int B, int S) {
+  BwdLayout b;
+  const int64_t M = (int64_t)B * S, H = s->hidden_size, I = s->intermediate_size;
+  int64_t o = 0;
+  auto take = [&](int64_t bytes) { int64_t r = o; o += al256(bytes); return r; };
+  b.g0 = take(M * H * 2); b.z = take(M * H * 2); b.y = take(M * H * 2); b.x1 = take(M * H * 2);
+  b.c = take(M * H * 2); b.q3 = take(M * 3 * H * 2); b.u = take(M * I * 2);
+  b.delta = take((int64_t)B * s->num_heads * S * 4);
+  int64_t sb = 0;
+  auto need = [&](int Mo, int No) { int64_t v = (int64_t)dw_splits(Mo, No, M) * Mo * No * 4; if (v > sb) sb = v; };
+  need(3 * H, H); need(H, H); need(I, H); need(H, I);
+  b.slab_bytes = sb;
+  b.slabs = take(sb);
+  b.total = o;
+  return b;
+}
+
+#define SITE_EMB 1u
+#define SITE_ATTN(l) (16u * ((l) + 1) + 0u)
+#define SITE_H1(l) (16u * ((l) + 1) + 1u)
+#define SITE_H2(l) (16u * ((l) + 1) + 2u)
+
+static int gemm(int al, int bl, int epi, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
+                int ldc, const float* bias, const void* aux, void* C2, int splitk, hipStream_t st) {
+  GemmArgs a{};
+  a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C; a.C2 = C2; a.bias = bias; a.aux = (const bf16_t*)aux;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  return gemm_dispatch(al, bl, epi, a, splitk, st);
+}
+#define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+}  // namespace czc
+
+using namespace czc;
+
+extern "C" int64_t czc_param_count(const czc_bert_shape* s) { return s ? param_layout(s).total : -1; }
+extern "C" int64_t czc_matrix_count(const czc_bert_shape* s) { return s ? param_layout(s).regionA : -1; }
+extern "C" int64_t czc_param_offset(const czc_bert_shape* s, int kind, int layer) {
+  if (!s || kind < 0 || kind >= CZC_P_KINDS || layer < 0 || layer >= s->num_layers) return -1;
+  return param_off(param_layout(s), kind, kind >= CZC_P_WORD ? 0 : layer);
+}
+extern "C" int64_t czc_encoder_workspace_bytes(const czc_bert_shape* s, int batch, int seq, int save_for_backward) {
+  if (!s || batch <= 0 || seq <= 0 || s->num_layers > 64) return -1;
+  return enc_layout(s, batch, seq, save_for_backward).total;
+}
+extern "C" int64_t czc_encoder_backward_scratch_bytes(const czc_bert_shape* s, int batch, int seq) {
+  if (!s || batch <= 0 || seq <= 0) return -1;
+  return bwd_layout(s, batch, seq).total;
+}
+
+extern "C" int czc_encoder_forward(const czc_bert_shape* s, const float* params_f32, const uint16_t* params_bf16,
+                                   const int64_t* ids, const uint8_t* mask, int batch, int seq, int pooling,
+                                   int normalize, int training, uint32_t seed, int save_for_backward, void* workspace,
+                                   int64_t workspace_bytes, float* emb_out, czc_stream_t stream) {
+  RC(shape_check("czc_encoder_forward", s));
+  CZC_REQUIRE(batch > 0 && seq > 0 && seq <= s->max_position && seq <= 512, "czc_encoder_forward: batch=%d seq=%d (max_position=%d, <= 512)", batch, seq, s->max_position);
+  CZC_REQUIRE(s->num_layers <= 64, "czc_encoder_forward: at most 64 layers");
+  CZC_REQUIRE(pooling == CZC_POOL_AVERAGE || pooling == CZC_POOL_CLS, "czc_encoder_forward: pooling=%d", pooling);
+  CZC_REQUIRE(params_f32 && params_bf16 && ids && mask && emb_out, "czc_encoder_forward: null argument");
+  const EncLayout e = enc_layout(s, batch, seq, save_for_backward);
+  CZC_REQUIRE(workspace && ((uintptr_t)workspace % 256) == 0 && workspace_bytes >= e.total,
+              "czc_encoder_forward: workspace %lld bytes < %lld needed (or not 256-B aligned)", (long long)workspace_bytes, (long long)e.total);
+  hipStream_t st = (hipStream_t)stream;
+  const ParamLayout pl = param_layout(s);
+  const int H = s->hidden_size, I = s->intermediate_size, L = s->num_layers, nh = s->num_heads;
+  const int M = batch * seq;
+  char* ws = (char*)workspace;
+  const float ph = training ? s->hidden_dropout : 0.f, pa = training ? s->attn_dropout : 0.f;
+  const float* P = params_f32;
+  const uint16_t* W = params_bf16;
+#define PF(kind, l) (P + param_off(pl, kind, l))
+#define WB(kind, l) (W + param_off(pl, kind, l))
+#define BUF(off) ((uint16_t*)(ws + (off)))
+#define FBUF(off) ((float*)(ws + (off)))
+
+  RC(czc_embed_ln_forward(ids, batch, seq, H, s->vocab_size, PF(CZC_P_WORD, 0), PF(CZC_P_POS, 0), PF(CZC_P_TYPE, 0),
+                          PF(CZC_P_ELNW, 0), PF(CZC_P_ELNB, 0), s->layer_norm_eps, ph, seed, SITE_EMB, BUF(e.x[0]),
+                          FBUF(e.st0), stream));
+  for (int l = 0; l < L; ++l) {
+    const LayerWs& w = e.layer[l];
+    RC(gemm(0, 0, EPI_BIAS, M, 3 * H, H, BUF(e.x[l]), H, WB(CZC_P_WQKV, l), H, BUF(w.qkv), 3 * H, PF(CZC_P_BQKV, l), nullptr, nullptr, 1, st));
+    RC(czc_attention_forward(BUF(w.qkv), mask, batch, seq, nh, pa, seed, SITE_ATTN(l), BUF(w.ctx), FBUF(w.lse), stream));
+    RC(gemm(0, 0, EPI_BIAS, M, H, H, BUF(w.ctx), H, WB(CZC_P_WO, l), H, BUF(w.y1), H, PF(CZC_P_BO, l), nullptr, nullptr, 1, st));
+    RC(czc_residual_ln_forward(BUF(w.y1), BUF(e.x[l]), M, H, PF(CZC_P_LN1W, l), PF(CZC_P_LN1B, l), s->layer_norm_eps, ph,
+                               seed, SITE_H1(l), BUF(w.x1), FBUF(w.st1), stream));
+    RC(gemm(0, 0, EPI_BIAS_GELU, M, I, H, BUF(w.x1), H, WB(CZC_P_W1, l), H, BUF(w.u), I, PF(CZC_P_B1, l), nullptr, BUF(w.hact), 1, st));
+    RC(gemm(0, 0, EPI_BIAS, M, H, I, BUF(w.hact), I, WB(CZC_P_W2, l), I, BUF(w.y2), H, PF(CZC_P_B2, l), nullptr, nullptr, 1, st));
+    RC(czc_residual_ln_forward(BUF(w.y2), BUF(w.x1), M, H, PF(CZC_P_LN2W, l), PF(CZC_P_LN2B, l), s->layer_norm_eps, ph,
+                               seed, SITE_H2(l), BUF(e.x[l + 1]), FBUF(w.st2), stream));
+  }
+  RC(czc_pool_forward(BUF(e.x[L]), mask, batch, seq, H, pooling, normalize, emb_out, FBUF(e.raw), stream));
+  return CZC_OK;
+}
+
+extern "C" int czc_encoder_backward(const czc_bert_shape* s, const float* params_f32, const uint16_t* params_bf16,
+                                    const int64_t* ids, const uint8_t* mask, int batch, int seq, int pooling,
+                                    int normalize, int training, uint32_t seed, void* workspace,
+                                    int64_t workspace_bytes, void* scratch, int64_t scratch_bytes, const float* d_emb,
+                                    float* grads_f32, int accumulate, czc_stream_t stream) {
+  RC(shape_check("czc_encoder_backward", s));
+  CZC_REQUIRE(batch > 0 && seq > 0 && seq <= 512 && s->num_layers <= 64, "czc_encoder_backward: batch=%d seq=%d", batch, seq);
+  CZC_REQUIRE(params_f32 && params_bf16 && ids && mask && d_emb && grads_f32, "czc_encoder_backward: null argument");
+  const EncLayout e = enc_layout(s, batch, seq, 1);
+  const BwdLayout bl = bwd_layout(s, batch, seq);
+  CZC_REQUIRE(workspace && ((uintptr_t)workspace % 256) == 0 && workspace_bytes >= e.total,
+              "czc_encoder_backward: workspace %lld bytes < %lld (it must be the save_for_backward=1 workspace)", (long long)workspace_bytes, (long long)e.total);
+  CZC_REQUIRE(scratch && ((uintptr_t)scratch % 256) == 0 && scratch_bytes >= bl.total,
+              "czc_encoder_backward: scratch %lld bytes < %lld", (long long)scratch_bytes, (long long)bl.total);
+  hipStream_t st = (hipStream_t)stream;
+  const ParamLayout pl = param_layout(s);
+  const int H = s->hidden_size, I = s->intermediate_size, L = s->num_layers, nh = s->num_heads;
+  const int M = batch * seq;
+  char* ws = (char*)workspace;
+  char* sc = (char*)scratch;
+  const float ph = training ? s->hidden_dropout : 0.f, pa = training ? s->attn_dropout : 0.f;
+  const float* P = params_f32;
+  const uint16_t* W = params_bf16;
+  float* G = grads_f32;
+#define GF(kind, l) (G + param_off(pl, kind, l))
+#define SBUF(off) ((uint16_t*)(sc + (off)))
+
+  if (!accumulate) {
+    // matrices are overwritten by the slab reduction; vectors and embeddings are accumulated by atomics
+    CZC_HIP(hipMemsetAsync(G + pl.regionA, 0, (size_t)(pl.total - pl.regionA) * 4, st));
+  }
+  uint16_t* g0 = SBUF(bl.g0); uint16_t* Z = SBUF(bl.z); uint16_t* Y = ph > 0.f ? SBUF(bl.y) : Z;
+  uint16_t* X1 = SBUF(bl.x1); uint16_t* C = SBUF(bl.c); uint16_t* Q3 = SBUF(bl.q3); uint16_t* U = SBUF(bl.u);
+  float* delta = (float*)(sc + bl.delta);
+  float* slabs = (float*)(sc + bl.slabs);
+
+  auto dweight = [&](int Mo, int No, const uint16_t* dY, int ldy, const uint16_t* X, int ldx, float* dst) -> int {
+    const int sp = dw_splits(Mo, No, M);
+    RC(gemm(1, 1, EPI_F32, Mo, No, M, dY, ldy, X, ldx, slabs, No, nullptr, nullptr, nullptr, sp, st));
+    return czc_reduce_slabs(slabs, sp, (int64_t)Mo * No, dst, accumulate, stream);
+  };
+
+  RC(czc_pool_backward(d_emb, FBUF(e.raw), mask, batch, seq, H, pooling, normalize, g0, stream));
+  for (int l = L - 1; l >= 0; --l) {
+    const LayerWs& w = e.layer[l];
+    // x[l+1] = LN(drop(y2) + x1)
+    RC(czc_residual_ln_backward(g0, nullptr, BUF(w.y2), BUF(w.x1), FBUF(w.st2), M, H, PF(CZC_P_LN2W, l), ph, seed,
+                                SITE_H2(l), Z, Y, GF(CZC_P_LN2W, l), GF(CZC_P_LN2B, l), GF(CZC_P_B2, l), stream));
+    RC(dweight(H, I, Y, H, BUF(w.hact), I, GF(CZC_P_W2, l)));
+    RC(gemm(0, 1, EPI_DGELU, M, I, H, Y, H, WB(CZC_P_W2, l), I, U, I, nullptr, BUF(w.u), nullptr, 1, st));
+    RC(czc_colsum_bf16(U, M, I, I, GF(CZC_P_B1, l), stream));
+    RC(dweight(I, H, U, I, BUF(w.x1), H, GF(CZC_P_W1, l)));
+    RC(gemm(0, 1, EPI_ADD, M, H, I, U, I, WB(CZC_P_W1, l), H, X1, H, nullptr, Z, nullptr, 1, st));
+    // x1 = LN(drop(y1) + x[l])
+    RC(czc_residual_ln_backward(X1, nullptr, BUF(w.y1), BUF(e.x[l]), FBUF(w.st1), M, H, PF(CZC_P_LN1W, l), ph, seed,
+                                SITE_H1(l), Z, Y, GF(CZC_P_LN1W, l), GF(CZC_P_LN1B, l), GF(CZC_P_BO, l), stream));
+    RC(dweight(H, H, Y, H, BUF(w.ctx), H, GF(CZC_P_WO, l)));
+    RC(gemm(0, 1, EPI_STORE, M, H, H, Y, H, WB(CZC_P_WO, l), H, C, H, nullptr, nullptr, nullptr, 1, st));
+    RC(czc_attention_backward(BUF(w.qkv), mask, BUF(w.ctx), C, FBUF(w.lse), batch, seq, nh, pa, seed, SITE_ATTN(l), delta, Q3, stream));
+    RC(czc_colsum_bf16(Q3, M, 3 * H, 3 * H, GF(CZC_P_BQKV, l), stream));
+    RC(dweight(3 * H, H, Q3, 3 * H, BUF(e.x[l]), H, GF(CZC_P_WQKV, l)));
+    RC(gemm(0, 1, EPI_ADD, M, H, 3 * H, Q3, 3 * H, WB(CZC_P_WQKV, l), H, g0, H, nullptr, Z, nullptr, 1, st));
+  }
+  RC(czc_embed_ln_backward(ids, batch, seq, H, s->vocab_size, PF(CZC_P_WORD, 0), PF(CZC_P_POS, 0), PF(CZC_P_TYPE, 0),
+                           PF(CZC_P_ELNW, 0), FBUF(e.st0), ph, seed, SITE_EMB, g0, GF(CZC_P_WORD, 0), GF(CZC_P_POS, 0),
+                           GF(CZC_P_TYPE, 0), GF(CZC_P_ELNW, 0), GF(CZC_P_ELNB, 0), stream));
+  return CZC_OK;
+}

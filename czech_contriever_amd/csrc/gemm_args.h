@@ -1,0 +1,34 @@
+// gemm_args.h — argument block and epilogue ids of the bf16 MFMA GEMM (gemm_bf16.hip).
+#pragma once
+#include "czc_common.h"
+
+namespace czc {
+
+struct GemmArgs {
+  const bf16_t* A; const bf16_t* B;
+  void* C; void* C2;
+  const float* bias; const bf16_t* aux;
+  const float* rowv;     // per-row vector (head: lse)
+  float* part;           // head partials [3][tilesN][M]
+  int M, N, K;
+  int lda, ldb, ldc;
+  int tiles_m, tiles_n;
+  int ktiles_per_split;  // K tiles handled by one split
+  float alpha;           // head: 1/T
+  float beta;            // head: eps/(K+1)
+};
+
+#define EPI_STORE 0
+#define EPI_BIAS 1
+#define EPI_BIAS_GELU 2
+#define EPI_DGELU 3
+#define EPI_ADD 4
+#define EPI_F32 5
+#define EPI_LSE 6       // head forward: per-row (max, sumexp, sum) partials of alpha*acc
+#define EPI_SOFTGRAD 7  // head backward: C = exp(alpha*acc - rowv[m]) - beta   (bf16)
+
+
+// checks shapes, picks the instantiation and launches; returns a CZC_* code
+int gemm_dispatch(int a_layout, int b_layout, int epi, GemmArgs a, int splitk, hipStream_t st);
+
+}  // namespace czc

@@ -1,0 +1,404 @@
+// gemm_bf16.hip — bf16 MFMA GEMM for gfx950, fp32 accumulate.
+//
+// One 256x256 output tile per 512-thread workgroup (8 waves as 2(M) x 4(N), 128x64 per wave),
+// K-step 64, v_mfma_f32_16x16x32_bf16.  Operand tiles go HBM -> LDS with global_load_lds_dwordx4
+// (no VGPR staging), double-buffered: the DMA of K-tile t+1 is in flight while tile t is
+// multiplied; one barrier per K-tile.  LDS: 2 buffers x (A 32 KiB + B 32 KiB) = 128 KiB.
+//
+// Each operand may be stored with the reduction index contiguous ("K-major": X[M][K], W[N][K]) or
+// with the free index contiguous ("MN-major": the operand of the weight-gradient and input-
+// gradient products).  K-major tiles are read with ds_read_b128, MN-major tiles with the
+// transposing ds_read_b64_tr_b16, so no operand is ever transposed in HBM.
+//   LDS images (conflict-free for the reads used):
+//     K-major  : [256 rows][8 chunks of 16 B], physical chunk = c ^ ((row >> 1) & 7)
+//     MN-major : 2 blocks of [64 k-rows][16 chunks], physical chunk = c ^ (((k&3)<<2) | ((k>>2)&3))
+//   global_load_lds writes LDS linearly (wave base + lane*16), so the swizzle is applied to the
+//   per-lane SOURCE address and again on the read.
+// 16-B chunks that fall outside the matrix are fetched from a zero page instead (per-lane source),
+// which gives exact tails in M, N and K without a second code path.
+//
+// The MFMA is issued as D = B_frag x A_frag, i.e. the accumulator tile is C^T: a lane owns one
+// output row m and four consecutive columns n, so bias loads are float4 and the bf16 tile is put
+// into LDS with 8-byte writes, then streamed out as whole 128-B row segments.
+#include "czc_common.h"
+#include "gemm_args.h"
+
+namespace czc {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int TILE_BYTES = 256 * 64 * 2;          // 32 KiB per operand tile
+constexpr int BUF_BYTES = 2 * TILE_BYTES;         // A + B
+constexpr int GEMM_LDS = 2 * BUF_BYTES;           // 128 KiB
+
+typedef const void __attribute__((address_space(1)))* gptr_t;
+typedef void __attribute__((address_space(3)))* lptr_t;
+
+__device__ __forceinline__ void glds16(const void* src, lptr_t dst) {
+  __builtin_amdgcn_global_load_lds((gptr_t)src, dst, 16, 0, 0);
+}
+
+// ---- staging -------------------------------------------------------------------------------
+// K-major operand: X[rows][ld], tile = rows [row0, row0+256) x k [k0, k0+64)
+__device__ __forceinline__ void stage_kmajor(const bf16_t* X, int ld, int row0, int nrows, int k0, int kdim,
+                                             unsigned char* tile, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = wave * 4 + i;            // 1-KiB piece: rows 8q .. 8q+7
+    const int r = 8 * q + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    const int gr = row0 + r, gk = k0 + c * 8;
+    const void* src = (gr < nrows && gk < kdim) ? (const void*)(X + (size_t)gr * ld + gk) : (const void*)g_zero16;
+    glds16(src, (lptr_t)(tile + q * 1024));
+  }
+}
+// MN-major operand: X[kdim][ld] (free index contiguous), tile = k [k0,k0+64) x cols [col0, col0+256)
+__device__ __forceinline__ void stage_mnmajor(const bf16_t* X, int ld, int col0, int ncols, int k0, int kdim,
+                                              unsigned char* tile, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = wave * 4 + i;            // piece q: block q>>4, k-rows 4*(q&15) .. +3
+    const int blk = q >> 4;
+    const int kr = 4 * (q & 15) + (lane >> 4);
+    const int ch = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
+    const int gk = k0 + kr, gc = col0 + blk * 128 + ch * 8;
+    const void* src = (gk < kdim && gc < ncols) ? (const void*)(X + (size_t)gk * ld + gc) : (const void*)g_zero16;
+    glds16(src, (lptr_t)(tile + q * 1024));
+  }
+}
+
+// ---- fragment reads --------------------------------------------------------------------------
+// K-major: rows [rbase + 16*i + (lane&15)], k-step ks (32 wide): lane reads k = 32ks + 8(lane>>4) .. +7
+__device__ __forceinline__ bf16x8 frag_kmajor(const unsigned char* tile, int rbase, int i, int ks, int lane) {
+  const int r = rbase + 16 * i + (lane & 15);
+  const int c = (4 * ks + (lane >> 4)) ^ (((lane & 15) >> 1) & 7);
+  return *(const bf16x8*)(tile + r * 128 + (c << 4));
+}
+// MN-major: columns [cbase + 16*i + (lane&15)] of the 256-wide tile, k-step ks
+__device__ __forceinline__ bf16x8 frag_mnmajor(const unsigned char* tile, int cbase, int i, int ks, int lane) {
+  const int col = cbase + 16 * i;                 // multiple of 16
+  const int blk = col >> 7, cb = col & 127;
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int row1 = 32 * ks + 8 * g + q, row2 = row1 + 4;
+  const int ch = (cb >> 3) + (p >> 1);
+  const int f1 = ((row1 & 3) << 2) | ((row1 >> 2) & 3);
+  const int f2 = ((row2 & 3) << 2) | ((row2 >> 2) & 3);
+  const unsigned char* b = tile + blk * 16384 + 8 * (p & 1);
+  typedef s16x4 __attribute__((address_space(3)))* trp_t;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(b + 256 * row1 + 16 * (ch ^ f1)));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(b + 256 * row2 + 16 * (ch ^ f2)));
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ void swizzle_tile(int bid, int nwg, int tiles_n, int& tm, int& tn) {
+  // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of
+  // tiles so the tiles_n blocks that share one A row-panel hit the same L2.  Bijective for any nwg.
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  tm = swz / tiles_n;
+  tn = swz - tm * tiles_n;
+}
+
+template <int AL, int BL, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  int tm, tn;
+  swizzle_tile(blockIdx.x, gridDim.x, a.tiles_n, tm, tn);
+  const int row0 = tm * BM, col0 = tn * BN;
+  const int split = blockIdx.y;
+  const int kt_total = (a.K + BK - 1) / BK;
+  const int kt_begin = split * a.ktiles_per_split;
+  int kt_end = kt_begin + a.ktiles_per_split;
+  if (kt_end > kt_total) kt_end = kt_total;
+  const int nt = kt_end - kt_begin;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto stage = [&](int t, int buf) {
+    unsigned char* ta = smem + buf * BUF_BYTES;
+    unsigned char* tb = ta + TILE_BYTES;
+    const int k0 = (kt_begin + t) * BK;
+    if (AL == 0) stage_kmajor(a.A, a.lda, row0, a.M, k0, a.K, ta, wave, lane);
+    else         stage_mnmajor(a.A, a.lda, row0, a.M, k0, a.K, ta, wave, lane);
+    if (BL == 0) stage_kmajor(a.B, a.ldb, col0, a.N, k0, a.K, tb, wave, lane);
+    else         stage_mnmajor(a.B, a.ldb, col0, a.N, k0, a.K, tb, wave, lane);
+  };
+
+  if (nt > 0) stage(0, 0);
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // tile t landed for every wave; buffer (t+1)&1 is free
+    if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
+    const unsigned char* ta = smem + (t & 1) * BUF_BYTES;
+    const unsigned char* tb = ta + TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 bf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        bf[j] = (BL == 0) ? frag_kmajor(tb, wn * 64, j, ks, lane) : frag_mnmajor(tb, wn * 64, j, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bf16x8 af = (AL == 0) ? frag_kmajor(ta, wm * 128, i, ks, lane) : frag_mnmajor(ta, wm * 128, i, ks, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af, acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---------------- epilogue ----------------
+  // acc[i][j][r] = C[row0 + wm*128 + 16i + (lane&15)][col0 + wn*64 + 16j + 4(lane>>4) + r]
+  const int mrow = lane & 15, nq = lane >> 4;
+
+  if (EPI == EPI_F32) {
+    float* C = (float*)a.C + (size_t)split * a.M * a.ldc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = row0 + wm * 128 + 16 * i + mrow;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = col0 + wn * 64 + 16 * j + 4 * nq;
+        if (m < a.M && n < a.N) *(f32x4*)(C + (size_t)m * a.ldc + n) = acc[i][j];
+      }
+    }
+    return;
+  }
+
+  if (EPI == EPI_LSE) {
+    // per-row partial (max, sum exp, sum) over this tile's valid columns of z = alpha*acc
+    __syncthreads();
+    float* red = (float*)smem;  // [3][4 wn][256 rows]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float mx = -1e30f, sm = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = col0 + wn * 64 + 16 * j + 4 * nq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float z = (n + r < a.N) ? acc[i][j][r] * a.alpha : -1e30f;
+          acc[i][j][r] = z;
+          mx = fmaxf(mx, z);
+          sm += (n + r < a.N) ? z : 0.f;
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float se = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) se += __expf(acc[i][j][r] - mx);
+      se += __shfl_xor(se, 16, 64); se += __shfl_xor(se, 32, 64);
+      sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
+      if (nq == 0) {
+        const int ml = wm * 128 + 16 * i + mrow;
+        red[(0 * 4 + wn) * 256 + ml] = mx;
+        red[(1 * 4 + wn) * 256 + ml] = se;
+        red[(2 * 4 + wn) * 256 + ml] = sm;
+      }
+    }
+    __syncthreads();
+    if (tid < 256) {
+      const int m = row0 + tid;
+      float mx = -1e30f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) mx = fmaxf(mx, red[(0 * 4 + w) * 256 + tid]);
+      float se = 0.f, sm = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        se += red[(1 * 4 + w) * 256 + tid] * __expf(red[(0 * 4 + w) * 256 + tid] - mx);
+        sm += red[(2 * 4 + w) * 256 + tid];
+      }
+      if (m < a.M) {
+        const size_t pl = (size_t)a.tiles_n * a.M;
+        a.part[0 * pl + (size_t)tn * a.M + m] = mx;
+        a.part[1 * pl + (size_t)tn * a.M + m] = se;
+        a.part[2 * pl + (size_t)tn * a.M + m] = sm;
+      }
+    }
+    return;
+  }
+
+  // bf16 outputs: registers -> LDS (per-wave 128 x 64 bf16 region, 16-B chunks XOR-swizzled by
+  // row&7) -> 16-B row segments -> global
+  __syncthreads();  // all waves are done reading the operand tiles
+  unsigned char* reg = smem + wave * 16384;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int rl = 16 * i + mrow;
+    float rv = 0.f;
+    if (EPI == EPI_SOFTGRAD) {
+      const int m = row0 + wm * 128 + rl;
+      rv = (m < a.M) ? a.rowv[m] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 v = acc[i][j];
+      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+        const int n = col0 + wn * 64 + 16 * j + 4 * nq;
+        if (n < a.N) {
+          const f32x4 b = *(const f32x4*)(a.bias + n);
+          v += b;
+        }
+      }
+      if (EPI == EPI_SOFTGRAD) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = __expf(v[r] * a.alpha - rv) - a.beta;
+      }
+      uint2 w;
+      w.x = pack2bf(v[0], v[1]);
+      w.y = pack2bf(v[2], v[3]);
+      const int chunk = (2 * j + (nq >> 1)) ^ (rl & 7);
+      *(uint2*)(reg + rl * 128 + chunk * 16 + (nq & 1) * 8) = w;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes are done (region is wave-private)
+  bf16_t* C = (bf16_t*)a.C;
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int idx = it * 64 + lane;
+    const int rl = idx >> 3, ch = idx & 7;
+    const int m = row0 + wm * 128 + rl;
+    const int n = col0 + wn * 64 + ch * 8;
+    if (m < a.M && n < a.N) {
+      uint4 v = *(const uint4*)(reg + rl * 128 + ((ch ^ (rl & 7)) << 4));
+      const size_t off = (size_t)m * a.ldc + n;
+      if (EPI == EPI_BIAS_GELU) {
+        *(uint4*)(C + off) = v;
+        uint4 g;
+        g.x = pack2bf(gelu_f(bflo(v.x)), gelu_f(bfhi(v.x)));
+        g.y = pack2bf(gelu_f(bflo(v.y)), gelu_f(bfhi(v.y)));
+        g.z = pack2bf(gelu_f(bflo(v.z)), gelu_f(bfhi(v.z)));
+        g.w = pack2bf(gelu_f(bflo(v.w)), gelu_f(bfhi(v.w)));
+        *(uint4*)((bf16_t*)a.C2 + off) = g;
+      } else if (EPI == EPI_DGELU) {
+        const uint4 u = *(const uint4*)(a.aux + off);
+        uint4 g;
+        g.x = pack2bf(bflo(v.x) * dgelu_f(bflo(u.x)), bfhi(v.x) * dgelu_f(bfhi(u.x)));
+        g.y = pack2bf(bflo(v.y) * dgelu_f(bflo(u.y)), bfhi(v.y) * dgelu_f(bfhi(u.y)));
+        g.z = pack2bf(bflo(v.z) * dgelu_f(bflo(u.z)), bfhi(v.z) * dgelu_f(bfhi(u.z)));
+        g.w = pack2bf(bflo(v.w) * dgelu_f(bflo(u.w)), bfhi(v.w) * dgelu_f(bfhi(u.w)));
+        *(uint4*)(C + off) = g;
+      } else if (EPI == EPI_ADD) {
+        const uint4 u = *(const uint4*)(a.aux + off);
+        uint4 g;
+        g.x = pack2bf(bflo(v.x) + bflo(u.x), bfhi(v.x) + bfhi(u.x));
+        g.y = pack2bf(bflo(v.y) + bflo(u.y), bfhi(v.y) + bfhi(u.y));
+        g.z = pack2bf(bflo(v.z) + bflo(u.z), bfhi(v.z) + bfhi(u.z));
+        g.w = pack2bf(bflo(v.w) + bflo(u.w), bfhi(v.w) + bfhi(u.w));
+        *(uint4*)(C + off) = g;
+      } else {
+        *(uint4*)(C + off) = v;
+      }
+    }
+  }
+}
+
+// ---- host launcher ---------------------------------------------------------------------------
+template <int AL, int BL, int EPI>
+static int launch(const GemmArgs& a, int splits, hipStream_t st) {
+  static bool attr_done = false;
+  auto kern = gemm_kernel<AL, BL, EPI>;
+  if (!attr_done) {
+    CZC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
+    attr_done = true;
+  }
+  dim3 grid(a.tiles_m * a.tiles_n, splits, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(512), GEMM_LDS, st, a);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
+template <int EPI>
+static int launch_layout(int al, int bl, const GemmArgs& a, int splits, hipStream_t st) {
+  if (al == 0 && bl == 0) return launch<0, 0, EPI>(a, splits, st);
+  if (al == 0 && bl == 1) return launch<0, 1, EPI>(a, splits, st);
+  if (al == 1 && bl == 1) return launch<1, 1, EPI>(a, splits, st);
+  set_error("czc_gemm: layout combination A=%d B=%d is not built (A MN-major needs B MN-major)", al, bl);
+  return CZC_ERR_INVALID;
+}
+
+int gemm_dispatch(int al, int bl, int epi, GemmArgs a, int splitk, hipStream_t st) {
+  CZC_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "czc_gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+  CZC_REQUIRE((a.lda % 8) == 0 && (a.ldb % 8) == 0 && (a.ldc % 8) == 0,
+              "czc_gemm: leading dimensions must be multiples of 8 (lda=%d ldb=%d ldc=%d)", a.lda, a.ldb, a.ldc);
+  CZC_REQUIRE((a.N % 8) == 0, "czc_gemm: N=%d must be a multiple of 8", a.N);
+  CZC_REQUIRE(((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.B % 16) == 0 && ((uintptr_t)a.C % 16) == 0,
+              "czc_gemm: operand pointers must be 16-byte aligned");
+  if (al == 0) CZC_REQUIRE((a.K % 8) == 0, "czc_gemm: K=%d must be a multiple of 8 for a K-major A", a.K);
+  if (al == 1) CZC_REQUIRE((a.M % 8) == 0, "czc_gemm: M=%d must be a multiple of 8 for an M-major A", a.M);
+  if (bl == 0) CZC_REQUIRE((a.K % 8) == 0, "czc_gemm: K=%d must be a multiple of 8 for a K-major B", a.K);
+  CZC_REQUIRE(splitk >= 1, "czc_gemm: splitk=%d", splitk);
+  CZC_REQUIRE(splitk == 1 || epi == EPI_F32, "czc_gemm: split-K needs the f32 slab epilogue");
+  a.tiles_m = ceil_div(a.M, BM);
+  a.tiles_n = ceil_div(a.N, BN);
+  const int kt = ceil_div(a.K, BK);
+  a.ktiles_per_split = ceil_div(kt, splitk);
+  switch (epi) {
+    case EPI_STORE: return launch_layout<EPI_STORE>(al, bl, a, splitk, st);
+    case EPI_BIAS: CZC_REQUIRE(a.bias, "czc_gemm: bias epilogue without bias"); return launch_layout<EPI_BIAS>(al, bl, a, splitk, st);
+    case EPI_BIAS_GELU:
+      CZC_REQUIRE(a.bias && a.C2, "czc_gemm: bias+gelu epilogue needs bias and C2");
+      return launch_layout<EPI_BIAS_GELU>(al, bl, a, splitk, st);
+    case EPI_DGELU: CZC_REQUIRE(a.aux, "czc_gemm: dgelu epilogue needs aux"); return launch_layout<EPI_DGELU>(al, bl, a, splitk, st);
+    case EPI_ADD: CZC_REQUIRE(a.aux, "czc_gemm: add epilogue needs aux"); return launch_layout<EPI_ADD>(al, bl, a, splitk, st);
+    case EPI_F32: return launch_layout<EPI_F32>(al, bl, a, splitk, st);
+    case EPI_LSE:
+      CZC_REQUIRE(al == 0 && bl == 0 && a.part, "czc_gemm: lse epilogue is K-major only");
+      return launch<0, 0, EPI_LSE>(a, 1, st);
+    case EPI_SOFTGRAD:
+      CZC_REQUIRE(al == 0 && bl == 0 && a.rowv, "czc_gemm: softgrad epilogue is K-major only");
+      return launch<0, 0, EPI_SOFTGRAD>(a, 1, st);
+  }
+  set_error("czc_gemm: unknown epilogue %d", epi);
+  return CZC_ERR_INVALID;
+}
+
+// slabs reduce:  dst (+)= sum_z slabs[z]
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslabs, int64_t n4, float* __restrict__ dst,
+                                    int accumulate) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 s = accumulate ? ((const f32x4*)dst)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < nslabs; ++z) s += ((const f32x4*)slabs)[(int64_t)z * n4 + i];
+    ((f32x4*)dst)[i] = s;
+  }
+}
+
+}  // namespace czc
+
+using namespace czc;
+
+extern "C" int czc_gemm_bf16(int a_layout, int b_layout, int epilogue, int M, int N, int K,
+                             const uint16_t* A, int lda, const uint16_t* B, int ldb,
+                             void* C, int ldc, const float* bias, const uint16_t* aux, void* C2,
+                             int splitk, czc_stream_t stream) {
+  CZC_REQUIRE(epilogue >= 0 && epilogue <= EPI_F32, "czc_gemm_bf16: epilogue %d", epilogue);
+  GemmArgs a{};
+  a.A = A; a.B = B; a.C = C; a.C2 = C2; a.bias = bias; a.aux = aux;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  return gemm_dispatch(a_layout, b_layout, epilogue, a, splitk, (hipStream_t)stream);
+}
+
+extern "C" int czc_reduce_slabs(const float* slabs, int nslabs, int64_t n, float* dst, int accumulate,
+                                czc_stream_t stream) {
+  CZC_REQUIRE(n % 4 == 0 && nslabs >= 1, "czc_reduce_slabs: n=%lld must be a multiple of 4", (long long)n);
+  const int64_t n4 = n / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slabs, nslabs, n4, dst,
+                     accumulate);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}

@@ -1,0 +1,275 @@
+// head.hip — MoCo InfoNCE head against the negative queue, for gfx950.
+//
+// Replaces src/moco.py:289-294 (q.queue logits), :323-330 (/T + cross_entropy, label smoothing),
+// :340-351 (loss / accuracy / stdq / stdk) and :277-287 (ring-buffer enqueue).
+//
+// The queue lives slot-major in bf16, queue_bf16[K][C] (row j = key j).  Forward: the logits
+// l_neg = q . queue^T are a bf16 MFMA GEMM (M = batch, N = K slots, reduction C) whose epilogue
+// never writes the [batch, K] matrix: every 256-slot tile leaves per-row (max, sum exp, sum)
+// partials and a tiny kernel folds them with the positive logit into lse, loss and accuracy.
+// Backward: P = softmax - smoothing is produced tile by tile in bf16 by the same GEMM with a
+// different epilogue (recomputing the logits from the saved lse), then dq = P . queue is a second
+// GEMM that reads the SAME queue rows through the transposing LDS read (queue as a [k][n]
+// operand), split over the K slots into fp32 slabs that one small kernel sums.
+#include "czc_common.h"
+#include "gemm_args.h"
+
+namespace czc {
+
+// q f32 [B,C] -> q_bf16 ; lpos[b] = sum_c q*k   (one wave per row)
+__global__ __launch_bounds__(256) void head_prep_kernel(const float* __restrict__ q, const float* __restrict__ k, int B,
+                                                        int C, bf16_t* __restrict__ qb, float* __restrict__ lpos) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  float s = 0.f;
+  for (int c = lane * 4; c < C; c += 256) {
+    const f32x4 a = *(const f32x4*)(q + (size_t)b * C + c), kk = *(const f32x4*)(k + (size_t)b * C + c);
+    s += a[0] * kk[0] + a[1] * kk[1] + a[2] * kk[2] + a[3] * kk[3];
+    uint2 w;
+    w.x = pack2bf(a[0], a[1]);
+    w.y = pack2bf(a[2], a[3]);
+    *(uint2*)(qb + (size_t)b * C + c) = w;
+  }
+  s = wave_sum(s);
+  if (lane == 0) lpos[b] = s;
+}
+
+// fold the per-tile partials with the positive logit.  One thread per row.
+__global__ __launch_bounds__(256) void head_final_kernel(const float* __restrict__ part, int tiles, int B, int Kq,
+                                                         const float* __restrict__ lpos, float invT, float ls,
+                                                         float* __restrict__ lse_out, float* __restrict__ rowloss,
+                                                         float* __restrict__ rowok) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const size_t pl = (size_t)tiles * B;
+  float mx = -1e30f;
+  for (int t = 0; t < tiles; ++t) mx = fmaxf(mx, part[(size_t)t * B + b]);
+  float se = 0.f, sm = 0.f;
+  for (int t = 0; t < tiles; ++t) {
+    se += part[pl + (size_t)t * B + b] * __expf(part[(size_t)t * B + b] - mx);
+    sm += part[2 * pl + (size_t)t * B + b];
+  }
+  const float z0 = lpos[b] * invT;
+  const float M = fmaxf(mx, z0);
+  const float tot = se * __expf(mx - M) + __expf(z0 - M);
+  const float lse = M + __logf(tot);
+  lse_out[b] = lse;
+  rowloss[b] = (1.0f - ls) * (lse - z0) + ls * (lse - (sm + z0) / (float)(Kq + 1));
+  rowok[b] = (z0 >= mx) ? 1.0f : 0.f;   // argmax picks column 0 on ties, as torch.argmax does
+}
+
+// stats[0] = mean loss, stats[1] = accuracy %, stats[2] = stats[3] = 0 (filled by colstd)
+__global__ __launch_bounds__(256) void head_mean_kernel(const float* __restrict__ rowloss, const float* __restrict__ rowok,
+                                                        int B, float* __restrict__ stats) {
+  __shared__ float red[8];
+  float a = 0.f, c = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) { a += rowloss[i]; c += rowok[i]; }
+  a = wave_sum(a); c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[4 + (threadIdx.x >> 6)] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    stats[0] = (red[0] + red[1] + red[2] + red[3]) / (float)B;
+    stats[1] = 100.0f * (red[4] + red[5] + red[6] + red[7]) / (float)B;
+    stats[2] = 0.f; stats[3] = 0.f; stats[4] = 0.f; stats[5] = 0.f; stats[6] = 0.f; stats[7] = 0.f;
+  }
+}
+
+// out[0] += mean_c std_b(x[:, c])  (unbiased, torch.std(x, dim=0).mean())
+__global__ __launch_bounds__(256) void colstd_kernel(const float* __restrict__ x, int B, int C, float* out) {
+  __shared__ float red[4];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  float sd = 0.f;
+  if (c < C) {
+    float m = 0.f;
+    for (int b = 0; b < B; ++b) m += x[(size_t)b * C + c];
+    m /= (float)B;
+    float v = 0.f;
+    for (int b = 0; b < B; ++b) { const float d = x[(size_t)b * C + c] - m; v += d * d; }
+    sd = sqrtf(v / (float)(B - 1));
+  }
+  sd = wave_sum(sd);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sd;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1] + red[2] + red[3]) / (float)C);
+}
+
+// dq = scale * (sum_z slab[z] + coef0[b] * k)
+__global__ __launch_bounds__(256) void head_bwd_final_kernel(const float* __restrict__ slabs, int nslabs, int B, int C,
+                                                             const float* __restrict__ k, const float* __restrict__ lpos,
+                                                             const float* __restrict__ lse, float invT, float ls, int Kq,
+                                                             float scale, float* __restrict__ dq) {
+  const int64_t n4 = (int64_t)B * C / 4;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int b = (int)((i * 4) / C);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < nslabs; ++z) s += ((const f32x4*)slabs)[(int64_t)z * n4 + i];
+  const float z0 = lpos[b] * invT;
+  const float coef0 = __expf(z0 - lse[b]) - (1.0f - ls) - ls / (float)(Kq + 1);
+  ((f32x4*)dq)[i] = (s + ((const f32x4*)k)[i] * coef0) * scale;
+}
+
+// ---- enqueue: 64 keys x 64 columns per block, transposed through LDS for the [C][K] fp32 copy ----
+__global__ __launch_bounds__(256) void enqueue_kernel(const float* __restrict__ keys, int n, int C, int Kq,
+                                                      bf16_t* __restrict__ qb, float* __restrict__ qf,
+                                                      const int64_t* __restrict__ ptr_dev) {
+  __shared__ float tile[64][65];
+  const int i0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int64_t ptr = ptr_dev[0];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int i = i0 + r, c = c0 + tx;
+    float v = 0.f;
+    if (i < n && c < C) {
+      v = keys[(size_t)i * C + c];
+      const int64_t slot = (ptr + i) % Kq;
+      qb[(size_t)slot * C + c] = f2bf(v);   // 64 lanes -> 128 contiguous bytes of one queue row
+    }
+    tile[r][tx] = v;
+  }
+  if (!qf) return;
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {       // r = column, tx = key: 64 lanes -> 256 contiguous bytes of queue_f32[c][.]
+    const int c = c0 + r, i = i0 + tx;
+    if (i < n && c < C) {
+      const int64_t slot = (ptr + i) % Kq;
+      qf[(size_t)c * Kq + slot] = tile[tx][r];
+    }
+  }
+}
+__global__ void advance_ptr_kernel(int64_t* ptr, int n, int Kq) { ptr[0] = (ptr[0] + n) % Kq; }
+
+// queue_bf16[K][C] = transpose(queue_f32[C][K])
+__global__ __launch_bounds__(256) void queue_import_kernel(const float* __restrict__ qf, int C, int Kq, bf16_t* __restrict__ qb) {
+  __shared__ float tile[64][65];
+  const int j0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int c = c0 + r, j = j0 + tx;
+    tile[r][tx] = (c < C && j < Kq) ? qf[(size_t)c * Kq + j] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int j = j0 + r, c = c0 + tx;
+    if (j < Kq && c < C) qb[(size_t)j * C + c] = f2bf(tile[tx][r]);
+  }
+}
+
+static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+struct HeadWs {
+  int64_t qb, lpos, part, rowloss, rowok, P, slabs, total;
+  int tiles, splits;
+};
+static HeadWs head_ws(int B, int C, int Kq) {
+  HeadWs w;
+  w.tiles = ceil_div(Kq, 256);
+  int kt = ceil_div(Kq, 64);
+  w.splits = kt < 84 ? kt : 84;
+  int64_t o = 0;
+  w.qb = o; o += align256((int64_t)B * C * 2);
+  w.lpos = o; o += align256((int64_t)B * 4);
+  w.part = o; o += align256((int64_t)3 * w.tiles * B * 4);
+  w.rowloss = o; o += align256((int64_t)B * 4);
+  w.rowok = o; o += align256((int64_t)B * 4);
+  w.P = o; o += align256((int64_t)B * Kq * 2);
+  w.slabs = o; o += align256((int64_t)w.splits * B * C * 4);
+  w.total = o;
+  return w;
+}
+
+}  // namespace czc
+
+using namespace czc;
+
+extern "C" int64_t czc_infonce_workspace_bytes(int batch, int dim, int queue_size) {
+  return head_ws(batch, dim, queue_size).total;
+}
+
+static int head_check(const char* who, int B, int C, int Kq, float T, float ls, void* ws, int64_t ws_bytes) {
+  CZC_REQUIRE(B > 1 && C > 0 && (C % 8) == 0 && Kq > 0 && (Kq % 8) == 0, "%s: batch=%d dim=%d queue=%d (dim, queue multiples of 8; batch >= 2)", who, B, C, Kq);
+  CZC_REQUIRE(T > 0.f && ls >= 0.f && ls < 1.f, "%s: temperature=%f label_smoothing=%f", who, T, ls);
+  CZC_REQUIRE(ws && ws_bytes >= head_ws(B, C, Kq).total && ((uintptr_t)ws % 256) == 0, "%s: workspace too small or unaligned (%lld < %lld)",
+              who, (long long)ws_bytes, (long long)head_ws(B, C, Kq).total);
+  return CZC_OK;
+}
+
+extern "C" int czc_infonce_forward(const float* q, const float* k, const uint16_t* queue_bf16, int batch, int dim,
+                                   int queue_size, float temperature, float label_smoothing, void* workspace,
+                                   int64_t workspace_bytes, float* lse_out, float* stats_out, czc_stream_t stream) {
+  if (int rc = head_check("czc_infonce_forward", batch, dim, queue_size, temperature, label_smoothing, workspace, workspace_bytes)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const HeadWs w = head_ws(batch, dim, queue_size);
+  char* base = (char*)workspace;
+  bf16_t* qb = (bf16_t*)(base + w.qb);
+  float* lpos = (float*)(base + w.lpos);
+  float* part = (float*)(base + w.part);
+  float* rowloss = (float*)(base + w.rowloss);
+  float* rowok = (float*)(base + w.rowok);
+  const float invT = 1.0f / temperature;
+  hipLaunchKernelGGL(head_prep_kernel, dim3(ceil_div(batch, 4)), dim3(256), 0, st, q, k, batch, dim, qb, lpos);
+  GemmArgs a{};
+  a.A = qb; a.B = queue_bf16; a.M = batch; a.N = queue_size; a.K = dim;
+  a.lda = dim; a.ldb = dim; a.ldc = queue_size; a.C = part; a.part = part; a.alpha = invT;
+  if (int rc = gemm_dispatch(0, 0, EPI_LSE, a, 1, st)) return rc;
+  hipLaunchKernelGGL(head_final_kernel, dim3(ceil_div(batch, 256)), dim3(256), 0, st, part, w.tiles, batch, queue_size,
+                     lpos, invT, label_smoothing, lse_out, rowloss, rowok);
+  hipLaunchKernelGGL(head_mean_kernel, dim3(1), dim3(256), 0, st, rowloss, rowok, batch, stats_out);
+  hipLaunchKernelGGL(colstd_kernel, dim3(ceil_div(dim, 256)), dim3(256), 0, st, q, batch, dim, stats_out + 2);
+  hipLaunchKernelGGL(colstd_kernel, dim3(ceil_div(dim, 256)), dim3(256), 0, st, k, batch, dim, stats_out + 3);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
+extern "C" int czc_infonce_backward(const float* q, const float* k, const uint16_t* queue_bf16, int batch, int dim,
+                                    int queue_size, float temperature, float label_smoothing, const float* lse,
+                                    float loss_scale, void* workspace, int64_t workspace_bytes, float* dq,
+                                    czc_stream_t stream) {
+  if (int rc = head_check("czc_infonce_backward", batch, dim, queue_size, temperature, label_smoothing, workspace, workspace_bytes)) return rc;
+  CZC_REQUIRE(((int64_t)batch * dim) % 4 == 0, "czc_infonce_backward: batch*dim must be a multiple of 4");
+  hipStream_t st = (hipStream_t)stream;
+  const HeadWs w = head_ws(batch, dim, queue_size);
+  char* base = (char*)workspace;
+  bf16_t* qb = (bf16_t*)(base + w.qb);
+  float* lpos = (float*)(base + w.lpos);
+  bf16_t* P = (bf16_t*)(base + w.P);
+  float* slabs = (float*)(base + w.slabs);
+  const float invT = 1.0f / temperature;
+  hipLaunchKernelGGL(head_prep_kernel, dim3(ceil_div(batch, 4)), dim3(256), 0, st, q, k, batch, dim, qb, lpos);
+  GemmArgs a{};
+  a.A = qb; a.B = queue_bf16; a.M = batch; a.N = queue_size; a.K = dim;
+  a.lda = dim; a.ldb = dim; a.ldc = queue_size; a.C = P; a.rowv = lse; a.alpha = invT;
+  a.beta = label_smoothing / (float)(queue_size + 1);
+  if (int rc = gemm_dispatch(0, 0, EPI_SOFTGRAD, a, 1, st)) return rc;
+  GemmArgs g{};
+  g.A = P; g.B = queue_bf16; g.M = batch; g.N = dim; g.K = queue_size;
+  g.lda = queue_size; g.ldb = dim; g.ldc = dim; g.C = slabs;
+  if (int rc = gemm_dispatch(0, 1, EPI_F32, g, w.splits, st)) return rc;
+  const int64_t n4 = (int64_t)batch * dim / 4;
+  hipLaunchKernelGGL(head_bwd_final_kernel, dim3((int)((n4 + 255) / 256)), dim3(256), 0, st, slabs, w.splits, batch, dim,
+                     k, lpos, lse, invT, label_smoothing, queue_size, loss_scale * invT / (float)batch, dq);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
+extern "C" int czc_enqueue(const float* keys, int n, int dim, int queue_size, uint16_t* queue_bf16, float* queue_f32,
+                           int64_t* queue_ptr, czc_stream_t stream) {
+  CZC_REQUIRE(n > 0 && dim > 0 && queue_size > 0 && n <= queue_size, "czc_enqueue: n=%d dim=%d queue=%d", n, dim, queue_size);
+  CZC_REQUIRE(queue_size % n == 0, "czc_enqueue: %d, %d (queue_size must be divisible by the gathered batch)", n, queue_size);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(enqueue_kernel, dim3(ceil_div(n, 64), ceil_div(dim, 64)), dim3(256), 0, st, keys, n, dim,
+                     queue_size, queue_bf16, queue_f32, queue_ptr);
+  hipLaunchKernelGGL(advance_ptr_kernel, dim3(1), dim3(1), 0, st, queue_ptr, n, queue_size);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
+extern "C" int czc_queue_import(const float* queue_f32, int dim, int queue_size, uint16_t* queue_bf16,
+                                czc_stream_t stream) {
+  CZC_REQUIRE(dim > 0 && queue_size > 0, "czc_queue_import: dim=%d queue=%d", dim, queue_size);
+  hipLaunchKernelGGL(queue_import_kernel, dim3(ceil_div(queue_size, 64), ceil_div(dim, 64)), dim3(256), 0,
+                     (hipStream_t)stream, queue_f32, dim, queue_size, queue_bf16);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}

@@ -1,0 +1,188 @@
+// optim.hip — whole-model elementwise kernels over the FLAT parameter arrays (gfx950, HBM-bound):
+// momentum EMA of the key encoder, AdamW, gradient norm / clip, fp32 -> bf16 mirror.
+// Each runs as ONE launch over all 108.9 M elements (the reference issues ~600 tiny launches for
+// the EMA alone, src/moco.py:260-269), 16 B per lane per access, grid-stride, and refreshes the
+// bf16 mirror of the matrix region in the same pass so no separate cast pass is needed.
+#include "czc_common.h"
+
+namespace czc {
+
+__device__ __forceinline__ void st_bf4g(bf16_t* p, f32x4 v) {
+  uint2 w;
+  w.x = pack2bf(v[0], v[1]);
+  w.y = pack2bf(v[2], v[3]);
+  *(uint2*)p = w;
+}
+
+// pk = pk*m + pq*(1-m): two rounded products and one rounded add, exactly like
+// `param_k.data * m + param_q.data * (1. - m)` in torch (no fused multiply-add).
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ pk, const float* __restrict__ pq, int64_t n4,
+                                                  int64_t n, float m, float om, bf16_t* __restrict__ pk_bf,
+                                                  int64_t n_bf) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 a = ((const f32x4*)pk)[i], b = ((const f32x4*)pq)[i];
+    f32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = __fadd_rn(__fmul_rn(a[j], m), __fmul_rn(b[j], om));
+    ((f32x4*)pk)[i] = r;
+    if (i * 4 + 3 < n_bf) st_bf4g(pk_bf + i * 4, r);
+  }
+  // tail (n not a multiple of 4)
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    const float r = __fadd_rn(__fmul_rn(pk[i], m), __fmul_rn(pq[i], om));
+    pk[i] = r;
+    if (i < n_bf) pk_bf[i] = f2bf(r);
+  }
+}
+
+struct AdamArgs {
+  float lr, beta1, beta2, eps, wd_factor;  // wd_factor = 1 - lr*weight_decay
+  float one_minus_b1, one_minus_b2, step_size, inv_bc2_sqrt, grad_scale;
+};
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, int64_t n4, int64_t n,
+                                                    AdamArgs a, const float* __restrict__ clip_coef,
+                                                    bf16_t* __restrict__ p_bf, int64_t n_bf) {
+  const float gs = a.grad_scale * (clip_coef ? clip_coef[0] : 1.0f);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 pp = ((const f32x4*)p)[i], gg = ((const f32x4*)g)[i] * gs, mm = ((const f32x4*)m)[i], vv = ((const f32x4*)v)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float x = pp[j] * a.wd_factor;
+      const float m1 = mm[j] + (gg[j] - mm[j]) * a.one_minus_b1;  // lerp, as torch
+      const float v1 = vv[j] * a.beta2 + gg[j] * gg[j] * a.one_minus_b2;
+      const float denom = sqrtf(v1) * a.inv_bc2_sqrt + a.eps;
+      x -= a.step_size * (m1 / denom);
+      pp[j] = x; mm[j] = m1; vv[j] = v1;
+    }
+    ((f32x4*)p)[i] = pp; ((f32x4*)m)[i] = mm; ((f32x4*)v)[i] = vv;
+    if (i * 4 + 3 < n_bf) st_bf4g(p_bf + i * 4, pp);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    const float gj = g[i] * gs;
+    float x = p[i] * a.wd_factor;
+    const float m1 = m[i] + (gj - m[i]) * a.one_minus_b1;
+    const float v1 = v[i] * a.beta2 + gj * gj * a.one_minus_b2;
+    x -= a.step_size * (m1 / (sqrtf(v1) * a.inv_bc2_sqrt + a.eps));
+    p[i] = x; m[i] = m1; v[i] = v1;
+    if (i < n_bf) p_bf[i] = f2bf(x);
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, int64_t n, float* partials) {
+  __shared__ float red[4];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float s = 0.f;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 a = ((const f32x4*)g)[i];
+    s += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float a = g[(n4 << 2) + threadIdx.x]; s += a * a; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partials, int np, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < np; i += 256) s += partials[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void clip_coef_kernel(const float* sumsq, float pre_scale, float max_norm, float* coef) {
+  const float c = max_norm / (sqrtf(sumsq[0]) * pre_scale + 1e-6f);
+  coef[0] = c < 1.0f ? c : 1.0f;
+}
+__global__ __launch_bounds__(256) void clamp_kernel(float* g, int64_t n, float lo, float hi) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] = fminf(fmaxf(g[i], lo), hi);
+}
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) st_bf4g(dst + i * 4, ((const f32x4*)src)[i]);
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const int64_t i = (n4 << 2) + threadIdx.x; dst[i] = f2bf(src[i]); }
+}
+
+static int flat_grid(int64_t n4) {
+  int64_t b = (n4 + 255) / 256;
+  if (b > 256 * 8) b = 256 * 8;   // 8 blocks per CU, grid-stride the rest
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace czc
+
+using namespace czc;
+
+extern "C" int czc_ema_update(float* pk, const float* pq, int64_t n, float m, float one_minus_m, uint16_t* pk_bf16,
+                              int64_t n_bf16, czc_stream_t stream) {
+  CZC_REQUIRE(n > 0 && n_bf16 >= 0 && n_bf16 <= n && (n_bf16 % 4) == 0, "czc_ema_update: n=%lld n_bf16=%lld",
+              (long long)n, (long long)n_bf16);
+  CZC_REQUIRE(((uintptr_t)pk % 16) == 0 && ((uintptr_t)pq % 16) == 0, "czc_ema_update: arrays must be 16-byte aligned");
+  hipLaunchKernelGGL(ema_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, pk, pq, n / 4, n, m,
+                     one_minus_m, pk_bf16, pk_bf16 ? n_bf16 : 0);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
+extern "C" int czc_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int step, float grad_scale,
+                              const float* clip_coef_dev, uint16_t* p_bf16, int64_t n_bf16, czc_stream_t stream) {
+  CZC_REQUIRE(n > 0 && step >= 1 && n_bf16 >= 0 && n_bf16 <= n && (n_bf16 % 4) == 0,
+              "czc_adamw_step: n=%lld step=%d n_bf16=%lld", (long long)n, step, (long long)n_bf16);
+  CZC_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
+              "czc_adamw_step: arrays must be 16-byte aligned");
+  AdamArgs a;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  a.wd_factor = (float)(1.0 - (double)lr * (double)weight_decay);
+  a.one_minus_b1 = (float)(1.0 - (double)beta1);
+  a.one_minus_b2 = (float)(1.0 - (double)beta2);
+  a.step_size = (float)((double)lr / bc1);
+  a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  a.grad_scale = grad_scale;
+  hipLaunchKernelGGL(adamw_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, n, a,
+                     clip_coef_dev, p_bf16, p_bf16 ? n_bf16 : 0);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
+extern "C" int czc_sumsq(const float* g, int64_t n, float* partials, float* out, czc_stream_t stream) {
+  CZC_REQUIRE(n > 0 && partials && out, "czc_sumsq: bad arguments");
+  const int nb = flat_grid(n / 4);  // <= 2048 <= 4096 partials
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, n, partials);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nb, out);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
+extern "C" int czc_clip_coef(const float* sumsq, float pre_scale, float max_norm, float* coef, czc_stream_t stream) {
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, pre_scale, max_norm, coef);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
+extern "C" int czc_clamp(float* g, int64_t n, float lo, float hi, czc_stream_t stream) {
+  CZC_REQUIRE(n > 0, "czc_clamp: n=%lld", (long long)n);
+  hipLaunchKernelGGL(clamp_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, g, n, lo, hi);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
+extern "C" int czc_cast_bf16(const float* src, uint16_t* dst, int64_t n, czc_stream_t stream) {
+  CZC_REQUIRE(n > 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 8) == 0, "czc_cast_bf16: n=%lld / alignment", (long long)n);
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}

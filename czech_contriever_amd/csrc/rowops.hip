@@ -1,0 +1,500 @@
+// rowops.hip — HBM-bound row kernels of the BERT encoder for gfx950:
+//   embedding gather + LayerNorm (+dropout) fwd/bwd, dropout + residual + LayerNorm fwd/bwd,
+//   masked mean / CLS pooling fwd/bwd, bf16 column sums (bias gradients), dropout-mask export.
+// One 64-lane wave owns one row at a time: lane l holds the float4 chunks l, l+64, l+128, l+192 of
+// the row (hidden <= 1024), so a row's mean / variance are two wave reductions, every global access
+// is 8 B (bf16) or 16 B (f32) per lane, contiguous across the wave, and the per-column gradient
+// sums (d gamma, d beta, d bias) stay in the SAME lane's registers across all rows a wave visits.
+#include "czc_common.h"
+
+namespace czc {
+
+constexpr int NIT = 4;  // hidden <= 64 lanes * 4 chunks * 4 elements = 1024
+
+__device__ __forceinline__ f32x4 ld_bf4(const bf16_t* p) {
+  const uint2 w = *(const uint2*)p;
+  return (f32x4){bflo(w.x), bfhi(w.x), bflo(w.y), bfhi(w.y)};
+}
+__device__ __forceinline__ void st_bf4(bf16_t* p, f32x4 v) {
+  uint2 w;
+  w.x = pack2bf(v[0], v[1]);
+  w.y = pack2bf(v[2], v[3]);
+  *(uint2*)p = w;
+}
+// keep-scale for 4 consecutive elements starting at even element index e (2 RNG pairs)
+__device__ __forceinline__ f32x4 drop_scale4(uint32_t seed, uint32_t site, uint32_t e, uint32_t thr, float inv_keep) {
+  const uint32_t r0 = czc_rng_pair(seed, site, e >> 1);
+  const uint32_t r1 = czc_rng_pair(seed, site, (e >> 1) + 1);
+  f32x4 s;
+  s[0] = ((r0 & 0xffffu) >= thr) ? inv_keep : 0.f;
+  s[1] = ((r0 >> 16) >= thr) ? inv_keep : 0.f;
+  s[2] = ((r1 & 0xffffu) >= thr) ? inv_keep : 0.f;
+  s[3] = ((r1 >> 16) >= thr) ? inv_keep : 0.f;
+  return s;
+}
+
+struct LnStat { float mean, rstd; };
+
+// mean / rstd of a row held as v[NIT] chunks (invalid chunks must be zero)
+__device__ __forceinline__ LnStat row_stats(const f32x4* v, int H, int lane, float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) s += v[it][0] + v[it][1] + v[it][2] + v[it][3];
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    if ((lane + 64 * it) * 4 < H) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float d = v[it][j] - mean; q += d * d; }
+    }
+  }
+  const float var = wave_sum(q) / (float)H;
+  return {mean, rsqrtf(var + eps)};
+}
+
+// ---------------------------------------------------------------------------------------------
+// x = LN(dropout(y) + resid)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void residual_ln_fwd_kernel(
+    const bf16_t* __restrict__ y, const bf16_t* __restrict__ resid, int rows, int H,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    uint32_t thr, float inv_keep, uint32_t seed, uint32_t site, bf16_t* __restrict__ x, float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const size_t base = (size_t)row * H;
+    f32x4 z[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = (lane + 64 * it) * 4;
+      z[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (c < H) {
+        f32x4 a = ld_bf4(y + base + c);
+        if (thr) a *= drop_scale4(seed, site, (uint32_t)(base + c), thr, inv_keep);
+        z[it] = a + ld_bf4(resid + base + c);
+      }
+    }
+    const LnStat st = row_stats(z, H, lane, eps);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = (lane + 64 * it) * 4;
+      if (c < H) {
+        const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
+        st_bf4(x + base + c, (z[it] - st.mean) * st.rstd * g + b);
+      }
+    }
+    if (lane == 0) { stats[2 * (size_t)row] = st.mean; stats[2 * (size_t)row + 1] = st.rstd; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward of the above.  dz_out: gradient w.r.t. (dropout(y) + resid); dy_out: w.r.t. y.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void flush_colsums(float* lds_acc, const f32x4 (&acc)[3][NIT], int H, int lane,
+                                              float* d0, float* d1, float* d2) {
+  // lds_acc [3][1024] zeroed by the caller; waves add their lane-private partial sums
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = (lane + 64 * it) * 4;
+      if (c < H) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(&lds_acc[s * 1024 + c + j], acc[s][it][j]);
+      }
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += blockDim.x) {
+    if (d0) unsafeAtomicAdd(d0 + c, lds_acc[c]);
+    if (d1) unsafeAtomicAdd(d1 + c, lds_acc[1024 + c]);
+    if (d2) unsafeAtomicAdd(d2 + c, lds_acc[2048 + c]);
+  }
+}
+
+__global__ __launch_bounds__(256) void residual_ln_bwd_kernel(
+    const bf16_t* __restrict__ dx, const bf16_t* __restrict__ dx2, const bf16_t* __restrict__ y,
+    const bf16_t* __restrict__ resid, const float* __restrict__ stats, int rows, int H,
+    const float* __restrict__ gamma, uint32_t thr, float inv_keep, uint32_t seed, uint32_t site,
+    bf16_t* __restrict__ dz_out, bf16_t* __restrict__ dy_out, float* d_gamma, float* d_beta, float* d_bias) {
+  __shared__ float lds_acc[3 * 1024];
+  for (int i = threadIdx.x; i < 3 * 1024; i += blockDim.x) lds_acc[i] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 acc[3][NIT];
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) acc[s][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 gm[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = (lane + 64 * it) * 4;
+    gm[it] = (c < H) ? *(const f32x4*)(gamma + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const size_t base = (size_t)row * H;
+    const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
+    f32x4 xh[NIT], gh[NIT], ds[NIT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = (lane + 64 * it) * 4;
+      xh[it] = gh[it] = ds[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (c < H) {
+        f32x4 a = ld_bf4(y + base + c);
+        if (thr) { ds[it] = drop_scale4(seed, site, (uint32_t)(base + c), thr, inv_keep); a *= ds[it]; }
+        const f32x4 z = a + ld_bf4(resid + base + c);
+        xh[it] = (z - mean) * rstd;
+        f32x4 g = ld_bf4(dx + base + c);
+        if (dx2) g += ld_bf4(dx2 + base + c);
+        acc[0][it] += g * xh[it];
+        acc[1][it] += g;
+        gh[it] = g * gm[it];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1 += gh[it][j]; s2 += gh[it][j] * xh[it][j]; }
+      }
+    }
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = (lane + 64 * it) * 4;
+      if (c < H) {
+        const f32x4 dz = (gh[it] - s1 - xh[it] * s2) * rstd;
+        st_bf4(dz_out + base + c, dz);
+        f32x4 dy = dz;
+        if (thr) dy *= ds[it];
+        if (thr || dy_out != dz_out) st_bf4(dy_out + base + c, dy);
+        acc[2][it] += dy;
+      }
+    }
+  }
+  flush_colsums(lds_acc, acc, H, lane, d_gamma, d_beta, d_bias);
+}
+
+// ---------------------------------------------------------------------------------------------
+// embeddings: x = dropout(LN(word[id] + pos[s] + type[0]))
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_ln_fwd_kernel(
+    const int64_t* __restrict__ ids, int rows, int S, int H, int vocab, const float* __restrict__ word,
+    const float* __restrict__ pos, const float* __restrict__ type0, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, uint32_t thr, float inv_keep, uint32_t seed, uint32_t site,
+    bf16_t* __restrict__ x, float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    int64_t id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const int s = row % S;
+    const size_t base = (size_t)row * H;
+    f32x4 z[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = (lane + 64 * it) * 4;
+      z[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (c < H) {
+        // same association as HF: (word + type) + pos
+        z[it] = (*(const f32x4*)(word + (size_t)id * H + c) + *(const f32x4*)(type0 + c)) +
+                *(const f32x4*)(pos + (size_t)s * H + c);
+      }
+    }
+    const LnStat st = row_stats(z, H, lane, eps);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = (lane + 64 * it) * 4;
+      if (c < H) {
+        const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
+        f32x4 o = (z[it] - st.mean) * st.rstd * g + b;
+        if (thr) o *= drop_scale4(seed, site, (uint32_t)(base + c), thr, inv_keep);
+        st_bf4(x + base + c, o);
+      }
+    }
+    if (lane == 0) { stats[2 * (size_t)row] = st.mean; stats[2 * (size_t)row + 1] = st.rstd; }
+  }
+}
+
+__global__ __launch_bounds__(256) void embed_ln_bwd_kernel(
+    const int64_t* __restrict__ ids, int rows, int S, int H, int vocab, const float* __restrict__ word,
+    const float* __restrict__ pos, const float* __restrict__ type0, const float* __restrict__ gamma,
+    const float* __restrict__ stats, uint32_t thr, float inv_keep, uint32_t seed, uint32_t site,
+    const bf16_t* __restrict__ dx, float* d_word, float* d_pos, float* d_type0, float* d_gamma, float* d_beta) {
+  __shared__ float lds_acc[3 * 1024];
+  for (int i = threadIdx.x; i < 3 * 1024; i += blockDim.x) lds_acc[i] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 acc[3][NIT];
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) acc[s][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 gm[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = (lane + 64 * it) * 4;
+    gm[it] = (c < H) ? *(const f32x4*)(gamma + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    int64_t id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const int s = row % S;
+    const size_t base = (size_t)row * H;
+    const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
+    f32x4 xh[NIT], gh[NIT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = (lane + 64 * it) * 4;
+      xh[it] = gh[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (c < H) {
+        const f32x4 z = (*(const f32x4*)(word + (size_t)id * H + c) + *(const f32x4*)(type0 + c)) +
+                        *(const f32x4*)(pos + (size_t)s * H + c);
+        xh[it] = (z - mean) * rstd;
+        f32x4 g = ld_bf4(dx + base + c);
+        if (thr) g *= drop_scale4(seed, site, (uint32_t)(base + c), thr, inv_keep);
+        acc[0][it] += g * xh[it];
+        acc[1][it] += g;
+        gh[it] = g * gm[it];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1 += gh[it][j]; s2 += gh[it][j] * xh[it][j]; }
+      }
+    }
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = (lane + 64 * it) * 4;
+      if (c < H) {
+        const f32x4 dz = (gh[it] - s1 - xh[it] * s2) * rstd;
+        acc[2][it] += dz;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          unsafeAtomicAdd(d_word + (size_t)id * H + c + j, dz[j]);
+          unsafeAtomicAdd(d_pos + (size_t)s * H + c + j, dz[j]);
+        }
+      }
+    }
+  }
+  flush_colsums(lds_acc, acc, H, lane, d_gamma, d_beta, d_type0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// pooling.  One 256-thread block per sequence, thread t owns columns 4t..4t+3.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict__ x, const uint8_t* __restrict__ mask,
+                                                       int S, int H, int pooling, int normalize,
+                                                       float* __restrict__ emb, float* __restrict__ raw) {
+  __shared__ float red[4];
+  __shared__ uint8_t m_s[512];
+  const int b = blockIdx.x, c = threadIdx.x * 4;
+  for (int s = threadIdx.x; s < S; s += 256) m_s[s] = mask[(size_t)b * S + s];
+  __syncthreads();
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+  int cnt = 0;
+  const bf16_t* xb = x + (size_t)b * S * H;
+  if (pooling == CZC_POOL_AVERAGE) {
+    for (int s = 0; s < S; ++s) {
+      if (m_s[s]) {
+        ++cnt;
+        if (c < H) sum += ld_bf4(xb + (size_t)s * H + c);
+      }
+    }
+    // torch: sum / count  (count == 0 gives nan/inf exactly as the reference's 0/0 would)
+    const float inv = 1.0f / (float)cnt;
+    sum = sum * inv;
+    if (cnt == 0) sum = sum * __builtin_nanf("");
+  } else {
+    if (m_s[0] && c < H) sum = ld_bf4(xb + c);
+  }
+  float nrm = 1.f;
+  if (normalize) {
+    const float ss = block_sum_256((c < H) ? (sum[0] * sum[0] + sum[1] * sum[1] + sum[2] * sum[2] + sum[3] * sum[3]) : 0.f, red);
+    nrm = fmaxf(sqrtf(ss), 1e-12f);
+  }
+  if (c < H) {
+    if (raw) *(f32x4*)(raw + (size_t)b * H + c) = sum;
+    *(f32x4*)(emb + (size_t)b * H + c) = normalize ? sum / nrm : sum;
+  }
+}
+
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ d_emb, const float* __restrict__ raw,
+                                                       const uint8_t* __restrict__ mask, int S, int H, int pooling,
+                                                       int normalize, bf16_t* __restrict__ dx) {
+  __shared__ float red[4];
+  __shared__ uint8_t m_s[512];
+  const int b = blockIdx.x, c = threadIdx.x * 4;
+  for (int s = threadIdx.x; s < S; s += 256) m_s[s] = mask[(size_t)b * S + s];
+  __syncthreads();
+  f32x4 g = {0.f, 0.f, 0.f, 0.f};
+  if (c < H) g = *(const f32x4*)(d_emb + (size_t)b * H + c);
+  if (normalize) {
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+    if (c < H) r = *(const f32x4*)(raw + (size_t)b * H + c);
+    const float ss = block_sum_256(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3], red);
+    const float dot = block_sum_256(r[0] * g[0] + r[1] * g[1] + r[2] * g[2] + r[3] * g[3], red);
+    const float nrm = sqrtf(ss);
+    if (nrm >= 1e-12f) g = (g - r * (dot / ss)) / nrm;   // d/dr of r/|r|
+    else g = g / 1e-12f;                                   // clamp_min branch of F.normalize
+  }
+  int cnt = 0;
+  for (int s = 0; s < S; ++s) cnt += m_s[s] ? 1 : 0;
+  bf16_t* db = dx + (size_t)b * S * H;
+  if (c < H) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    if (pooling == CZC_POOL_AVERAGE) {
+      const f32x4 gs = g * (1.0f / (float)cnt);
+      for (int s = 0; s < S; ++s) st_bf4(db + (size_t)s * H + c, m_s[s] ? gs : zero);
+    } else {
+      for (int s = 0; s < S; ++s) st_bf4(db + (size_t)s * H + c, (s == 0 && m_s[0]) ? g : zero);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// column sums of a bf16 matrix: col[n] += sum_m x[m][n]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, int rows, int cols, int ld,
+                                                     int rows_per_block, float* col) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 8;
+  if (c >= cols) return;
+  const int r0 = blockIdx.y * rows_per_block;
+  int r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int r = r0; r < r1; ++r) {
+    const uint4 w = *(const uint4*)(x + (size_t)r * ld + c);
+    a[0] += bflo(w.x); a[1] += bfhi(w.x); a[2] += bflo(w.y); a[3] += bfhi(w.y);
+    a[4] += bflo(w.z); a[5] += bfhi(w.z); a[6] += bflo(w.w); a[7] += bfhi(w.w);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) unsafeAtomicAdd(col + c + j, a[j]);
+}
+
+__global__ void dropout_mask_kernel(uint32_t seed, uint32_t site, uint32_t thr, int64_t n, uint8_t* keep) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    keep[i] = czc_keep(seed, site, (uint32_t)i, thr) ? 1 : 0;
+}
+
+static int row_grid(int rows) {
+  int g = ceil_div(rows, 4);
+  return g > 2048 ? 2048 : (g < 1 ? 1 : g);
+}
+static bool hidden_ok(int H) { return H > 0 && H <= 1024 && (H % 8) == 0; }
+
+}  // namespace czc
+
+using namespace czc;
+
+#define DROP_ARGS(p) \
+  const uint32_t thr = (p) > 0.f ? czc_drop_thr(p) : 0u; \
+  const float inv_keep = (p) > 0.f ? 1.0f / (1.0f - (p)) : 1.0f
+
+extern "C" int czc_residual_ln_forward(const uint16_t* y, const uint16_t* resid, int rows, int hidden,
+                                       const float* gamma, const float* beta, float eps, float dropout_p,
+                                       uint32_t seed, uint32_t site, uint16_t* x, float* stats, czc_stream_t stream) {
+  CZC_REQUIRE(hidden_ok(hidden), "czc_residual_ln_forward: hidden=%d must be a multiple of 8 and <= 1024", hidden);
+  CZC_REQUIRE(rows > 0 && dropout_p >= 0.f && dropout_p < 1.f, "czc_residual_ln_forward: rows=%d p=%f", rows, dropout_p);
+  DROP_ARGS(dropout_p);
+  hipLaunchKernelGGL(residual_ln_fwd_kernel, dim3(row_grid(rows)), dim3(256), 0, (hipStream_t)stream, y, resid, rows,
+                     hidden, gamma, beta, eps, thr, inv_keep, seed, site, x, stats);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
+extern "C" int czc_residual_ln_backward(const uint16_t* dx, const uint16_t* dx2, const uint16_t* y,
+                                        const uint16_t* resid, const float* stats, int rows, int hidden,
+                                        const float* gamma, float dropout_p, uint32_t seed, uint32_t site,
+                                        uint16_t* dz_out, uint16_t* dy_out, float* d_gamma, float* d_beta,
+                                        float* d_bias, czc_stream_t stream) {
+  CZC_REQUIRE(hidden_ok(hidden), "czc_residual_ln_backward: hidden=%d must be a multiple of 8 and <= 1024", hidden);
+  CZC_REQUIRE(rows > 0 && dropout_p >= 0.f && dropout_p < 1.f, "czc_residual_ln_backward: rows=%d p=%f", rows, dropout_p);
+  CZC_REQUIRE(dz_out && dy_out, "czc_residual_ln_backward: outputs missing");
+  CZC_REQUIRE(!(dropout_p > 0.f && dz_out == dy_out), "czc_residual_ln_backward: dy_out must differ from dz_out when p > 0");
+  DROP_ARGS(dropout_p);
+  int g = row_grid(rows);
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(residual_ln_bwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, dx, dx2, y, resid, stats, rows,
+                     hidden, gamma, thr, inv_keep, seed, site, dz_out, dy_out, d_gamma, d_beta, d_bias);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
+extern "C" int czc_embed_ln_forward(const int64_t* ids, int batch, int seq, int hidden, int vocab, const float* word,
+                                    const float* pos, const float* type0, const float* gamma, const float* beta,
+                                    float eps, float dropout_p, uint32_t seed, uint32_t site, uint16_t* x,
+                                    float* stats, czc_stream_t stream) {
+  CZC_REQUIRE(hidden_ok(hidden), "czc_embed_ln_forward: hidden=%d must be a multiple of 8 and <= 1024", hidden);
+  CZC_REQUIRE(batch > 0 && seq > 0 && vocab > 0, "czc_embed_ln_forward: batch=%d seq=%d vocab=%d", batch, seq, vocab);
+  DROP_ARGS(dropout_p);
+  const int rows = batch * seq;
+  hipLaunchKernelGGL(embed_ln_fwd_kernel, dim3(row_grid(rows)), dim3(256), 0, (hipStream_t)stream, ids, rows, seq,
+                     hidden, vocab, word, pos, type0, gamma, beta, eps, thr, inv_keep, seed, site, x, stats);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
+extern "C" int czc_embed_ln_backward(const int64_t* ids, int batch, int seq, int hidden, int vocab, const float* word,
+                                     const float* pos, const float* type0, const float* gamma, const float* stats,
+                                     float dropout_p, uint32_t seed, uint32_t site, const uint16_t* dx, float* d_word,
+                                     float* d_pos, float* d_type0, float* d_gamma, float* d_beta,
+                                     czc_stream_t stream) {
+  CZC_REQUIRE(hidden_ok(hidden), "czc_embed_ln_backward: hidden=%d must be a multiple of 8 and <= 1024", hidden);
+  CZC_REQUIRE(batch > 0 && seq > 0 && vocab > 0, "czc_embed_ln_backward: batch=%d seq=%d vocab=%d", batch, seq, vocab);
+  DROP_ARGS(dropout_p);
+  const int rows = batch * seq;
+  int g = row_grid(rows);
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, ids, rows, seq, hidden, vocab,
+                     word, pos, type0, gamma, stats, thr, inv_keep, seed, site, dx, d_word, d_pos, d_type0, d_gamma,
+                     d_beta);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
+extern "C" int czc_pool_forward(const uint16_t* x, const uint8_t* mask, int batch, int seq, int hidden, int pooling,
+                                int normalize, float* emb, float* raw_out, czc_stream_t stream) {
+  CZC_REQUIRE(hidden_ok(hidden), "czc_pool_forward: hidden=%d must be a multiple of 8 and <= 1024", hidden);
+  CZC_REQUIRE(batch > 0 && seq > 0 && seq <= 512, "czc_pool_forward: batch=%d seq=%d (seq <= 512)", batch, seq);
+  CZC_REQUIRE(pooling == CZC_POOL_AVERAGE || pooling == CZC_POOL_CLS, "czc_pool_forward: pooling=%d", pooling);
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, x, mask, seq, hidden, pooling,
+                     normalize, emb, raw_out);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
+extern "C" int czc_pool_backward(const float* d_emb, const float* raw, const uint8_t* mask, int batch, int seq,
+                                 int hidden, int pooling, int normalize, uint16_t* dx, czc_stream_t stream) {
+  CZC_REQUIRE(hidden_ok(hidden), "czc_pool_backward: hidden=%d must be a multiple of 8 and <= 1024", hidden);
+  CZC_REQUIRE(batch > 0 && seq > 0 && seq <= 512, "czc_pool_backward: batch=%d seq=%d (seq <= 512)", batch, seq);
+  CZC_REQUIRE(!normalize || raw, "czc_pool_backward: normalize needs the raw embedding");
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, d_emb, raw, mask, seq, hidden,
+                     pooling, normalize, dx);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
+extern "C" int czc_colsum_bf16(const uint16_t* x, int rows, int cols, int ld, float* col, czc_stream_t stream) {
+  CZC_REQUIRE(rows > 0 && cols > 0 && (cols % 8) == 0 && (ld % 8) == 0, "czc_colsum_bf16: rows=%d cols=%d ld=%d", rows, cols, ld);
+  const int rpb = 128;
+  dim3 grid(ceil_div(cols, 2048), ceil_div(rows, rpb));
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, rpb, col);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
+extern "C" int czc_dropout_mask(uint32_t seed, uint32_t site, float p, int64_t n, uint8_t* keep, czc_stream_t stream) {
+  CZC_REQUIRE(p >= 0.f && p < 1.f && n > 0 && n < (1ll << 32), "czc_dropout_mask: p=%f n=%lld", p, (long long)n);
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, seed, site,
+                     p > 0.f ? czc_drop_thr(p) : 0u, n, keep);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}

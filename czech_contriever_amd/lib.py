@@ -1,0 +1,127 @@
+"""ctypes binding of libczc.so (include/czc.h).  Fails loudly: there is no CPU fallback.
+
+Every wrapper takes torch tensors (device memory is torch's), checks dtype / device / contiguity,
+passes raw pointers plus the CURRENT torch stream, and raises RuntimeError with czc_last_error()
+when the library refuses a call."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libczc.so")
+
+vp, i32, i64, u32, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_float
+
+
+class BertShape(C.Structure):
+    _fields_ = [("vocab_size", C.c_int32), ("hidden_size", C.c_int32), ("num_layers", C.c_int32),
+                ("num_heads", C.c_int32), ("intermediate_size", C.c_int32), ("max_position", C.c_int32),
+                ("type_vocab_size", C.c_int32), ("layer_norm_eps", C.c_float), ("hidden_dropout", C.c_float),
+                ("attn_dropout", C.c_float)]
+
+
+SP = C.POINTER(BertShape)
+
+# name -> (restype, argtypes); mirrors include/czc.h one to one
+SIGNATURES = {
+    "czc_last_error": (C.c_char_p, []),
+    "czc_abi_version": (i32, []),
+    "czc_param_count": (i64, [SP]),
+    "czc_matrix_count": (i64, [SP]),
+    "czc_param_offset": (i64, [SP, i32, i32]),
+    "czc_encoder_workspace_bytes": (i64, [SP, i32, i32, i32]),
+    "czc_encoder_backward_scratch_bytes": (i64, [SP, i32, i32]),
+    "czc_encoder_forward": (i32, [SP, vp, vp, vp, vp, i32, i32, i32, i32, i32, u32, i32, vp, i64, vp, vp]),
+    "czc_encoder_backward": (i32, [SP, vp, vp, vp, vp, i32, i32, i32, i32, i32, u32, vp, i64, vp, i64, vp, vp, i32, vp]),
+    "czc_infonce_workspace_bytes": (i64, [i32, i32, i32]),
+    "czc_infonce_forward": (i32, [vp, vp, vp, i32, i32, i32, f32, f32, vp, i64, vp, vp, vp]),
+    "czc_infonce_backward": (i32, [vp, vp, vp, i32, i32, i32, f32, f32, vp, f32, vp, i64, vp, vp]),
+    "czc_enqueue": (i32, [vp, i32, i32, i32, vp, vp, vp, vp]),
+    "czc_queue_import": (i32, [vp, i32, i32, vp, vp]),
+    "czc_ema_update": (i32, [vp, vp, i64, f32, f32, vp, i64, vp]),
+    "czc_adamw_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp, vp, i64, vp]),
+    "czc_sumsq": (i32, [vp, i64, vp, vp, vp]),
+    "czc_clip_coef": (i32, [vp, f32, f32, vp, vp]),
+    "czc_clamp": (i32, [vp, i64, f32, f32, vp]),
+    "czc_cast_bf16": (i32, [vp, vp, i64, vp]),
+    "czc_gemm_bf16": (i32, [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, vp]),
+    "czc_reduce_slabs": (i32, [vp, i32, i64, vp, i32, vp]),
+    "czc_attention_forward": (i32, [vp, vp, i32, i32, i32, f32, u32, u32, vp, vp, vp]),
+    "czc_attention_backward": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32, u32, u32, vp, vp, vp]),
+    "czc_embed_ln_forward": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, f32, u32, u32, vp, vp, vp]),
+    "czc_embed_ln_backward": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, u32, u32, vp, vp, vp, vp, vp, vp, vp]),
+    "czc_residual_ln_forward": (i32, [vp, vp, i32, i32, vp, vp, f32, f32, u32, u32, vp, vp, vp]),
+    "czc_residual_ln_backward": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, f32, u32, u32, vp, vp, vp, vp, vp, vp]),
+    "czc_colsum_bf16": (i32, [vp, i32, i32, i32, vp, vp]),
+    "czc_pool_forward": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "czc_pool_backward": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "czc_dropout_mask": (i32, [u32, u32, f32, i64, vp, vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libczc.so (building it first if hipcc is present and it is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from . import build as _b
+        _b.build()
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m czech_contriever_amd.build`")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = a symbol czc.h declares is not exported
+        fn.restype, fn.argtypes = res, args
+    if lib.czc_abi_version() != 1:
+        raise RuntimeError("libczc.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().czc_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int):
+    if rc != 0:
+        raise RuntimeError(f"libczc: {last_error()} (code {rc})")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor], dtype=None) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libczc needs device tensors (there is no CPU path)")
+    if not t.is_contiguous():
+        raise RuntimeError("libczc needs contiguous tensors")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"libczc: expected {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def shape_struct(cfg, hidden_dropout=None, attn_dropout=None) -> BertShape:
+    """cfg: anything with HF BertConfig attribute names."""
+    g = lambda k, d=None: getattr(cfg, k, d)
+    return BertShape(
+        int(g("vocab_size")), int(g("hidden_size")), int(g("num_hidden_layers")), int(g("num_attention_heads")),
+        int(g("intermediate_size")), int(g("max_position_embeddings")), int(g("type_vocab_size", 2)),
+        float(g("layer_norm_eps", 1e-12)),
+        float(g("hidden_dropout_prob", 0.1) if hidden_dropout is None else hidden_dropout),
+        float(g("attention_probs_dropout_prob", 0.1) if attn_dropout is None else attn_dropout))
+
+
+P_KINDS = ["WQKV", "WO", "W1", "W2", "BQKV", "BO", "LN1W", "LN1B", "B1", "B2", "LN2W", "LN2B",
+           "WORD", "POS", "TYPE", "ELNW", "ELNB"]
+P = {k: i for i, k in enumerate(P_KINDS)}
+EPI = {"store": 0, "bias": 1, "bias_gelu": 2, "dgelu": 3, "add": 4, "f32": 5}

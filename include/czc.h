@@ -1,0 +1,245 @@
+/* czc.h — C ABI of libczc.so: the MI355X (gfx950) MoCo contrastive-training hot path.
+ *
+ * The reference (Ajchler/czech-contriever) is pure Python and has no FFI of its own; its hot path
+ * is the chain train.py:263-264,324 -> src/moco.py:296-353 -> src/contriever.py:17-55 (HF BertModel)
+ * plus src/dist_utils.py:29-37 and src/utils.py:137-150.  Each entry point below names the reference
+ * lines whose arithmetic it replaces.  INTEGRATION.md shows the ctypes stubs a maintainer of the
+ * reference would add to bind them.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch-allocated); the library allocates
+ *     nothing persistent and never synchronises: all work is enqueued on `stream` (a hipStream_t
+ *     passed as void*), so calls may be captured into a hipGraph.
+ *   - bf16 tensors are raw uint16 storage; "f32" is float; ids are int64; masks are uint8 (0/1),
+ *     which is the memory layout of torch.bool.
+ *   - return value: 0 = CZC_OK, otherwise an error code; czc_last_error() gives the message
+ *     (thread-local).  Nothing is launched when an argument check fails.
+ *   - one process per GPU; calls are made from one host thread per process.
+ */
+#ifndef CZC_H_
+#define CZC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CZC_OK 0
+#define CZC_ERR_INVALID 1
+#define CZC_ERR_HIP 2
+
+#define CZC_ABI_VERSION 1
+
+typedef void* czc_stream_t; /* hipStream_t */
+
+const char* czc_last_error(void);
+int czc_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Encoder shape (HF BertConfig as read by src/moco.py:226-229 / src/contriever.py:11-13)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct czc_bert_shape {
+  int32_t vocab_size;
+  int32_t hidden_size;        /* multiple of 64, <= 1024 */
+  int32_t num_layers;
+  int32_t num_heads;          /* hidden_size / num_heads must be 64 */
+  int32_t intermediate_size;  /* multiple of 64 */
+  int32_t max_position;
+  int32_t type_vocab_size;
+  float layer_norm_eps;
+  float hidden_dropout;       /* HF hidden_dropout_prob (0.1) */
+  float attn_dropout;         /* HF attention_probs_dropout_prob (0.1) */
+} czc_bert_shape;
+
+/* Flat parameter layout.  One encoder = one fp32 array of czc_param_count() elements:
+ *   region A (matrices, also mirrored in bf16): per layer [Wqkv 3H*H | Wo H*H | W1 I*H | W2 H*I]
+ *   region B (vectors): per layer [bqkv 3H | bo H | ln1.w H | ln1.b H | b1 I | b2 H | ln2.w H | ln2.b H]
+ *   region C (embeddings): word V*H | pos P*H | type T*H | emb_ln.w H | emb_ln.b H
+ * All Linear weights keep the HF [out,in] row-major orientation.
+ * czc_param_offset(kind, layer) returns the element offset of one tensor. */
+enum czc_param_kind {
+  CZC_P_WQKV = 0, CZC_P_WO, CZC_P_W1, CZC_P_W2,                         /* region A */
+  CZC_P_BQKV, CZC_P_BO, CZC_P_LN1W, CZC_P_LN1B, CZC_P_B1, CZC_P_B2, CZC_P_LN2W, CZC_P_LN2B, /* B */
+  CZC_P_WORD, CZC_P_POS, CZC_P_TYPE, CZC_P_ELNW, CZC_P_ELNB,            /* region C */
+  CZC_P_KINDS
+};
+int64_t czc_param_count(const czc_bert_shape* s);
+int64_t czc_matrix_count(const czc_bert_shape* s); /* size of region A = length of the bf16 mirror */
+int64_t czc_param_offset(const czc_bert_shape* s, int kind, int layer);
+
+/* ---------------------------------------------------------------------------------------------
+ * Encoder forward / backward  — replaces Contriever.forward (src/contriever.py:17-55) and its
+ * autograd backward (train.py:264); arithmetic of HF BertEmbeddings/BertSelfAttention/
+ * BertSelfOutput/BertIntermediate/BertOutput.
+ * ------------------------------------------------------------------------------------------- */
+#define CZC_POOL_AVERAGE 0
+#define CZC_POOL_CLS 1
+
+/* bytes of workspace czc_encoder_forward needs.  save_for_backward=1 keeps every activation the
+ * backward re-reads (about (8H+2I)*2 bytes per token per layer); 0 keeps one layer's scratch. */
+int64_t czc_encoder_workspace_bytes(const czc_bert_shape* s, int batch, int seq, int save_for_backward);
+/* extra scratch (gradient temporaries, split-K slabs) czc_encoder_backward needs */
+int64_t czc_encoder_backward_scratch_bytes(const czc_bert_shape* s, int batch, int seq);
+
+/* emb[b, :] = pool(BERT(ids, mask)) ; optional L2 normalisation (F.normalize eps 1e-12).
+ *   params_f32 : flat fp32 parameters (layout above);  params_bf16: bf16 mirror of region A
+ *   ids  int64 [batch, seq];  mask uint8 [batch, seq] (1 = token, 0 = padding; key padding mask
+ *   for attention, and pooling weights)
+ *   training != 0 applies dropout with the counter RNG keyed by `seed` (pass the same seed to
+ *   czc_encoder_backward).  workspace: czc_encoder_workspace_bytes(..) bytes, 256-B aligned.
+ *   emb_out f32 [batch, hidden]. */
+int czc_encoder_forward(const czc_bert_shape* s, const float* params_f32, const uint16_t* params_bf16,
+                        const int64_t* ids, const uint8_t* mask, int batch, int seq,
+                        int pooling, int normalize, int training, uint32_t seed,
+                        int save_for_backward, void* workspace, int64_t workspace_bytes,
+                        float* emb_out, czc_stream_t stream);
+
+/* grads_f32 (flat, same layout as params) += d(sum(emb * d_emb))/d(params)  when accumulate != 0,
+ * or is overwritten when accumulate == 0.  `workspace` is the one the matching forward filled. */
+int czc_encoder_backward(const czc_bert_shape* s, const float* params_f32, const uint16_t* params_bf16,
+                         const int64_t* ids, const uint8_t* mask, int batch, int seq,
+                         int pooling, int normalize, int training, uint32_t seed,
+                         void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes,
+                         const float* d_emb, float* grads_f32, int accumulate, czc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * MoCo head — replaces MoCo._compute_logits + "/ temperature" + F.cross_entropy + stats
+ * (src/moco.py:289-294, 323-330, 340-351) and their backward w.r.t. q.
+ * The negative queue is held slot-major in bf16: queue_bf16 [K, C] (row j = key j), so the
+ * forward reads rows as the MFMA B operand and the enqueue writes whole rows.
+ * ------------------------------------------------------------------------------------------- */
+int64_t czc_infonce_workspace_bytes(int batch, int dim, int queue_size);
+
+/* stats_out f32[8]: 0 loss (mean), 1 accuracy in percent, 2 stdq, 3 stdk (src/moco.py:343-351),
+ * 4..7 reserved.  lse_out f32 [batch] is kept for the backward. */
+int czc_infonce_forward(const float* q, const float* k, const uint16_t* queue_bf16,
+                        int batch, int dim, int queue_size, float temperature, float label_smoothing,
+                        void* workspace, int64_t workspace_bytes,
+                        float* lse_out, float* stats_out, czc_stream_t stream);
+
+/* dq f32 [batch, dim] = loss_scale * d(loss)/d(q) */
+int czc_infonce_backward(const float* q, const float* k, const uint16_t* queue_bf16,
+                         int batch, int dim, int queue_size, float temperature, float label_smoothing,
+                         const float* lse, float loss_scale,
+                         void* workspace, int64_t workspace_bytes, float* dq, czc_stream_t stream);
+
+/* Ring-buffer enqueue — replaces MoCo._dequeue_and_enqueue after the gather (src/moco.py:277-287).
+ * keys f32 [n, dim] (all ranks, rank order).  Writes rows [ptr, ptr+n) of queue_bf16 [K, dim] and,
+ * when queue_f32 != NULL, the same keys into the reference-layout fp32 buffer queue_f32 [dim, K]
+ * (columns ptr..ptr+n) that the checkpoint stores.  queue_ptr (int64[1], device) is read on the
+ * device and advanced to (ptr + n) % K: no host synchronisation. */
+int czc_enqueue(const float* keys, int n, int dim, int queue_size, uint16_t* queue_bf16,
+                float* queue_f32, int64_t* queue_ptr, czc_stream_t stream);
+
+/* queue_bf16 [K, dim] <- transpose(queue_f32 [dim, K])  (after load_state_dict / init) */
+int czc_queue_import(const float* queue_f32, int dim, int queue_size, uint16_t* queue_bf16,
+                     czc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Momentum EMA — replaces MoCo._momentum_update_key_encoder (src/moco.py:260-269) for the whole
+ * flat parameter array in one launch:  pk = pk*m + pq*(1-m)  (two rounded products, one add, as
+ * torch computes it), and refreshes the first n_bf16 elements of the bf16 mirror of pk.
+ * ------------------------------------------------------------------------------------------- */
+int czc_ema_update(float* pk, const float* pq, int64_t n, float m, float one_minus_m,
+                   uint16_t* pk_bf16, int64_t n_bf16, czc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * AdamW — replaces torch.optim.AdamW.step as configured by utils.set_optim (src/utils.py:137-150):
+ * decoupled weight decay, bias-corrected moments.  `step` counts from 1.  grad_scale multiplies
+ * the gradient first (1/world_size for the all-reduced mean, times the clip coefficient read from
+ * clip_coef_dev[0] when that pointer is not NULL).  Also refreshes the bf16 mirror.
+ * ------------------------------------------------------------------------------------------- */
+int czc_adamw_step(float* p, const float* g, float* m, float* v, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                   float grad_scale, const float* clip_coef_dev,
+                   uint16_t* p_bf16, int64_t n_bf16, czc_stream_t stream);
+
+/* sum of squares of g[0..n) -> out[0] (f32, device); out2 partial workspace of >= 4096 floats */
+int czc_sumsq(const float* g, int64_t n, float* partials, float* out, czc_stream_t stream);
+/* coef[0] = min(1, max_norm / (sqrt(sumsq[0]) * pre_scale + 1e-6))  (torch clip_grad_norm_) */
+int czc_clip_coef(const float* sumsq, float pre_scale, float max_norm, float* coef, czc_stream_t stream);
+int czc_clamp(float* g, int64_t n, float lo, float hi, czc_stream_t stream);
+
+/* dst_bf16[i] = bf16(src[i]) */
+int czc_cast_bf16(const float* src, uint16_t* dst, int64_t n, czc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Building blocks, exported so that tests can check each kernel against the oracle.
+ * ------------------------------------------------------------------------------------------- */
+#define CZC_LAYOUT_KMAJOR 0  /* reduction index contiguous:  A[M][K] / B[N][K] */
+#define CZC_LAYOUT_MNMAJOR 1 /* free index contiguous:       A[K][M] / B[K][N] */
+
+#define CZC_EPI_STORE 0      /* C bf16 = acc */
+#define CZC_EPI_BIAS 1       /* C bf16 = acc + bias[n] */
+#define CZC_EPI_BIAS_GELU 2  /* C = u = acc + bias ; C2 = gelu(u) */
+#define CZC_EPI_DGELU 3      /* C = acc * gelu'(aux[m][n]) */
+#define CZC_EPI_ADD 4        /* C = acc + aux[m][n] */
+#define CZC_EPI_F32 5        /* C f32 [splitk][M][ldc] = partial acc (no reduction) */
+
+/* C[M,N] = A . B over K.  bf16 in, fp32 accumulate.  ld* in elements.  aux/C2 share ldc.
+ * splitk > 1 only with CZC_EPI_F32 (slab z at C + z*M*ldc). */
+int czc_gemm_bf16(int a_layout, int b_layout, int epilogue, int M, int N, int K,
+                  const uint16_t* A, int lda, const uint16_t* B, int ldb,
+                  void* C, int ldc, const float* bias, const uint16_t* aux, void* C2,
+                  int splitk, czc_stream_t stream);
+
+/* dst (+)= sum_z slabs[z]  (n elements each) */
+int czc_reduce_slabs(const float* slabs, int nslabs, int64_t n, float* dst, int accumulate,
+                     czc_stream_t stream);
+
+/* qkv bf16 [batch*seq, 3H] (Q | K | V, head h at columns h*64) -> ctx bf16 [batch*seq, H];
+ * lse f32 [batch, heads, seq] (natural log).  dropout_p on the probabilities when > 0. */
+int czc_attention_forward(const uint16_t* qkv, const uint8_t* mask, int batch, int seq, int heads,
+                          float dropout_p, uint32_t seed, uint32_t site,
+                          uint16_t* ctx, float* lse, czc_stream_t stream);
+/* dqkv bf16 [batch*seq, 3H];  delta f32 [batch, heads, seq] is scratch */
+int czc_attention_backward(const uint16_t* qkv, const uint8_t* mask, const uint16_t* ctx,
+                           const uint16_t* dctx, const float* lse, int batch, int seq, int heads,
+                           float dropout_p, uint32_t seed, uint32_t site,
+                           float* delta, uint16_t* dqkv, czc_stream_t stream);
+
+/* x = dropout(LN(word[ids] + pos[s] + type[0]))  bf16 [M,H];  stats f32 [M,2] = (mean, rstd) */
+int czc_embed_ln_forward(const int64_t* ids, int batch, int seq, int hidden, int vocab,
+                         const float* word, const float* pos, const float* type0,
+                         const float* gamma, const float* beta, float eps,
+                         float dropout_p, uint32_t seed, uint32_t site,
+                         uint16_t* x, float* stats, czc_stream_t stream);
+int czc_embed_ln_backward(const int64_t* ids, int batch, int seq, int hidden, int vocab,
+                          const float* word, const float* pos, const float* type0,
+                          const float* gamma, const float* stats,
+                          float dropout_p, uint32_t seed, uint32_t site, const uint16_t* dx,
+                          float* d_word, float* d_pos, float* d_type0, float* d_gamma, float* d_beta,
+                          czc_stream_t stream);
+
+/* x = LN(dropout(y) + resid) ; y already holds the dense bias */
+int czc_residual_ln_forward(const uint16_t* y, const uint16_t* resid, int rows, int hidden,
+                            const float* gamma, const float* beta, float eps,
+                            float dropout_p, uint32_t seed, uint32_t site,
+                            uint16_t* x, float* stats, czc_stream_t stream);
+/* dz = dLN(dx [+ dx2]) ;  dz_out = dz (residual branch), dy_out = dropout-masked dz (dense branch);
+ * d_gamma/d_beta/d_bias (+)= column sums (atomic fp32).  dy_out may equal dz_out when p == 0. */
+int czc_residual_ln_backward(const uint16_t* dx, const uint16_t* dx2, const uint16_t* y,
+                             const uint16_t* resid, const float* stats, int rows, int hidden,
+                             const float* gamma, float dropout_p, uint32_t seed, uint32_t site,
+                             uint16_t* dz_out, uint16_t* dy_out,
+                             float* d_gamma, float* d_beta, float* d_bias, czc_stream_t stream);
+
+/* col[n] += sum_m x[m][n]  (bias gradients) */
+int czc_colsum_bf16(const uint16_t* x, int rows, int cols, int ld, float* col, czc_stream_t stream);
+
+/* masked mean / CLS pooling (+ optional normalise); raw_out f32 [batch,H] keeps the
+ * un-normalised embedding for the backward (may be NULL when normalize == 0) */
+int czc_pool_forward(const uint16_t* x, const uint8_t* mask, int batch, int seq, int hidden,
+                     int pooling, int normalize, float* emb, float* raw_out, czc_stream_t stream);
+int czc_pool_backward(const float* d_emb, const float* raw, const uint8_t* mask, int batch, int seq,
+                      int hidden, int pooling, int normalize, uint16_t* dx, czc_stream_t stream);
+
+/* fill keep[i] (uint8) for element i of a dropout site: lets tests hand the oracle the same mask */
+int czc_dropout_mask(uint32_t seed, uint32_t site, float p, int64_t n, uint8_t* keep, czc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CZC_H_ */

@@ -1,0 +1,388 @@
+"""GPU parity tests for every kernel behind the C ABI (libczc.so), each against a plain fp32
+reference of the same op computed from the SAME bf16-rounded inputs.  Run with `-m gpu` on MI355X.
+Tolerances are written next to each check: bf16 outputs carry 2^-9 relative rounding; fp32
+accumulations over K terms differ from torch's by summation order only."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from czech_contriever_amd import ops as _ops
+    from czech_contriever_amd import lib
+    lib.load()
+    return _ops
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=F32):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(dev())
+
+
+def report(name, got, ref, atol, rtol):
+    got, ref = got.float(), ref.float()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    if bad.any() or not torch.isfinite(got).all():
+        idx = torch.nonzero(bad)[:5].tolist()
+        worst = err.argmax()
+        raise AssertionError(
+            f"{name}: {int(bad.sum())}/{bad.numel()} out of tolerance; max err {float(err.max()):.4e} at flat {int(worst)} "
+            f"(got {float(got.flatten()[worst]):.6f} ref {float(ref.flatten()[worst]):.6f}); first bad idx {idx}; "
+            f"finite={bool(torch.isfinite(got).all())}")
+
+
+# ------------------------------------------------------------------------------------------------
+# flat elementwise kernels
+# ------------------------------------------------------------------------------------------------
+def test_ema_exact(ops):
+    n = 1_000_003
+    pk, pq = rnd(n, seed=1), rnd(n, seed=2)
+    nb = 4096
+    pkb = torch.zeros(nb, dtype=BF16, device=dev())
+    m = 0.9995
+    ref = pk * m + pq * (1.0 - m)      # torch on the GPU: two rounded products, one add
+    ref_cpu = pk.cpu() * m + pq.cpu() * (1.0 - m)
+    ops.ema_update(pk, pq, m, pkb, nb)
+    assert torch.equal(pk.cpu(), ref_cpu), (pk.cpu() - ref_cpu).abs().max()
+    assert torch.equal(pk, ref)
+    assert torch.equal(pkb, ref[:nb].to(BF16))
+
+
+def test_adamw_matches_torch(ops):
+    n = 100_003
+    p0 = rnd(n, seed=3)
+    p = p0.clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    pb = torch.zeros(1024, dtype=BF16, device=dev())
+    tp = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([tp], lr=1e-2, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01)
+    for step in range(1, 6):
+        g = rnd(n, seed=10 + step, scale=0.5)
+        tp.grad = g.clone()
+        opt.step()
+        ops.adamw_step(p, g, m, v, 1e-2, 0.9, 0.98, 1e-6, 0.01, step, 1.0, None, pb, 1024)
+        report(f"adamw step {step}", p, tp.detach(), 1e-6, 1e-5)
+    assert torch.equal(pb, p[:1024].to(BF16))
+
+
+def test_grad_norm_clip_and_scale(ops):
+    n = 300_001
+    g = rnd(n, seed=5)
+    partials = torch.empty(4096, dtype=F32, device=dev())
+    ss = torch.empty(1, dtype=F32, device=dev())
+    coef = torch.empty(1, dtype=F32, device=dev())
+    ops.sumsq(g, partials, ss)
+    ref = float((g.double() ** 2).sum())
+    assert abs(float(ss) - ref) <= 1e-5 * ref
+    ops.clip_coef(ss, 1.0, 2.0, coef)
+    assert abs(float(coef) - min(1.0, 2.0 / (math.sqrt(ref) + 1e-6))) < 1e-6
+    # the coefficient is applied inside AdamW: compare with torch clipping then stepping
+    p = rnd(n, seed=6)
+    tp = torch.nn.Parameter(p.clone())
+    tp.grad = g.clone()
+    torch.nn.utils.clip_grad_norm_([tp], 2.0)
+    opt = torch.optim.AdamW([tp], lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01)
+    opt.step()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    ops.adamw_step(p, g, m, v, 1e-3, 0.9, 0.98, 1e-6, 0.01, 1, 1.0, coef)
+    report("clipped adamw", p, tp.detach(), 1e-6, 1e-5)
+    g2 = g.clone()
+    ops.clamp_(g2, -0.5, 0.25)
+    assert torch.equal(g2, g.clamp(-0.5, 0.25))
+    dst = torch.empty(n, dtype=BF16, device=dev())
+    ops.cast_bf16(g, dst)
+    assert torch.equal(dst, g.to(BF16))
+
+
+def test_enqueue_ring_buffer(ops):
+    C, K, n = 64, 512, 64
+    qf = torch.nn.functional.normalize(rnd(C, K, seed=7), dim=0).contiguous()
+    qb = torch.empty(K, C, dtype=BF16, device=dev())
+    ops.queue_import(qf, qb)
+    assert torch.equal(qb, qf.t().contiguous().to(BF16))
+    ptr = torch.zeros(1, dtype=torch.int64, device=dev())
+    ref = qf.clone()
+    p = 0
+    for step in range(10):  # wraps after 8
+        keys = rnd(n, C, seed=100 + step)
+        ops.enqueue(keys, qb, qf, ptr)
+        ref[:, p:p + n] = keys.t()
+        p = (p + n) % K
+        assert int(ptr) == p
+    assert torch.equal(qf, ref)
+    assert torch.equal(qb, ref.t().contiguous().to(BF16))
+    with pytest.raises(RuntimeError):
+        ops.enqueue(rnd(48, C), qb, qf, ptr)  # 512 % 48 != 0: the reference asserts (src/moco.py:279-281)
+
+
+def test_dropout_mask_rate_and_numpy_restatement(ops):
+    from tests.dropout_ref import keep_mask
+    n = 1 << 20
+    keep = ops.dropout_mask(1234, 17, 0.1, n, dev()).cpu().numpy()
+    assert abs(keep.mean() - 0.9) < 2e-3
+    assert np.array_equal(keep, keep_mask(1234, 17, 0.1, n))
+
+
+# ------------------------------------------------------------------------------------------------
+# row kernels
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,H", [(37, 128), (1000, 768), (5, 1024)])
+def test_residual_ln_fwd_bwd(ops, rows, H):
+    y, resid = rnd(rows, H, seed=1, dtype=BF16), rnd(rows, H, seed=2, dtype=BF16)
+    gamma = 1.0 + 0.1 * rnd(H, seed=3)
+    beta = 0.1 * rnd(H, seed=4)
+    eps = 1e-12
+    x, stats = ops.residual_ln_forward(y, resid, gamma, beta, eps)
+    z = (y.float() + resid.float()).requires_grad_(True)
+    gp, bp = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(z, (H,), gp, bp, eps)
+    report("ln fwd", x, ref, 2e-2, 8e-3)  # bf16 output
+    report("ln mean", stats[:, 0], z.mean(-1), 1e-5, 1e-5)
+    dx = rnd(rows, H, seed=5, dtype=BF16)
+    dx2 = rnd(rows, H, seed=6, dtype=BF16)
+    ref.backward(dx.float() + dx2.float())
+    dg, db, dbias = (torch.zeros(H, device=dev()) for _ in range(3))
+    dz, dy = ops.residual_ln_backward(dx, dx2, y, resid, stats, gamma, dg, db, dbias)
+    report("ln dz", dz, z.grad, 3e-2, 1e-2)
+    report("ln dgamma", dg, gp.grad, 2e-3 * math.sqrt(rows), 1e-3)
+    report("ln dbeta", db, bp.grad, 2e-3 * math.sqrt(rows), 1e-3)
+    report("ln dbias", dbias, z.grad.sum(0), 3e-3 * math.sqrt(rows), 1e-3)
+
+
+def test_residual_ln_dropout_consistency(ops):
+    from tests.dropout_ref import keep_mask
+    rows, H, p, seed, site = 64, 768, 0.1, 99, 33
+    y, resid = rnd(rows, H, seed=1, dtype=BF16), rnd(rows, H, seed=2, dtype=BF16)
+    gamma, beta = 1.0 + 0.1 * rnd(H, seed=3), 0.1 * rnd(H, seed=4)
+    keep = torch.from_numpy(keep_mask(seed, site, p, rows * H).reshape(rows, H)).to(dev()).float()
+    x, stats = ops.residual_ln_forward(y, resid, gamma, beta, 1e-12, p, seed, site)
+    yv = y.float().requires_grad_(True)
+    z = yv * keep / (1 - p) + resid.float()
+    ref = torch.nn.functional.layer_norm(z, (H,), gamma, beta, 1e-12)
+    report("ln+dropout fwd", x, ref, 2e-2, 8e-3)
+    dx = rnd(rows, H, seed=5, dtype=BF16)
+    ref.backward(dx.float())
+    dg, db, dbias = (torch.zeros(H, device=dev()) for _ in range(3))
+    dz, dy = ops.residual_ln_backward(dx, None, y, resid, stats, gamma, dg, db, dbias, p, seed, site)
+    report("ln+dropout dy", dy, yv.grad, 3e-2, 1e-2)
+
+
+def test_embed_ln_fwd_bwd(ops):
+    B, S, H, V = 3, 40, 768, 1000
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, V, (B, S), generator=g).to(dev())
+    ids[0, :5] = 7  # repeated ids: scatter-add collisions
+    word, pos, typ = rnd(V, H, seed=1, scale=0.05), rnd(64, H, seed=2, scale=0.05), rnd(2, H, seed=3, scale=0.05)
+    gamma, beta = 1.0 + 0.1 * rnd(H, seed=4), 0.1 * rnd(H, seed=5)
+    x, stats = ops.embed_ln_forward(ids, word, pos, typ[0].contiguous(), gamma, beta, 1e-12)
+    wp, pp, tp = (t.clone().requires_grad_(True) for t in (word, pos, typ))
+    gp, bp = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z = wp[ids] + tp[0][None, None] + pp[:S][None]
+    ref = torch.nn.functional.layer_norm(z, (H,), gp, bp, 1e-12)
+    report("embed fwd", x.view(B, S, H), ref, 2e-2, 8e-3)
+    dx = rnd(B * S, H, seed=6, dtype=BF16)
+    ref.backward(dx.float().view(B, S, H))
+    dw, dp, dt = torch.zeros_like(word), torch.zeros_like(pos), torch.zeros(H, device=dev())
+    dg, db = torch.zeros(H, device=dev()), torch.zeros(H, device=dev())
+    ops.embed_ln_backward(ids, word, pos, typ[0].contiguous(), gamma, stats, dx, dw, dp, dt, dg, db)
+    report("d_word", dw, wp.grad, 5e-4, 1e-3)
+    report("d_pos", dp, pp.grad, 5e-4, 1e-3)
+    report("d_type0", dt, tp.grad[0], 2e-3, 1e-3)
+    report("d_gamma", dg, gp.grad, 2e-3, 1e-3)
+    report("d_beta", db, bp.grad, 2e-3, 1e-3)
+
+
+@pytest.mark.parametrize("pooling,normalize", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_pool_fwd_bwd(ops, pooling, normalize):
+    B, S, H = 5, 24, 768
+    x = rnd(B * S, H, seed=1, dtype=BF16)
+    mask = torch.zeros(B, S, dtype=torch.bool, device=dev())
+    for b, n in enumerate([24, 17, 1, 9, 24]):
+        mask[b, :n] = True
+    emb, raw = ops.pool_forward(x, mask, B, S, pooling, normalize)
+    xv = x.float().view(B, S, H).requires_grad_(True)
+    lh = xv.masked_fill(~mask[..., None], 0.0)
+    ref = lh.sum(1) / mask.sum(1)[..., None] if pooling == 0 else lh[:, 0]
+    if normalize:
+        ref = torch.nn.functional.normalize(ref, dim=-1)
+    report("pool fwd", emb, ref, 1e-5, 1e-5)
+    de = rnd(B, H, seed=2)
+    ref.backward(de)
+    dx = ops.pool_backward(de, raw, mask, B, S, pooling, normalize)
+    report("pool bwd", dx.view(B, S, H), xv.grad, 1e-3, 8e-3)
+
+
+def test_colsum(ops):
+    x = rnd(1000, 2304, seed=1, dtype=BF16)
+    col = torch.zeros(2304, device=dev())
+    ops.colsum(x, col)
+    report("colsum", col, x.float().sum(0), 2e-3, 1e-4)
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------
+def _mk(M, N, K, al, bl, seed):
+    a = rnd(M, K, seed=seed, scale=0.5, dtype=BF16)
+    b = rnd(N, K, seed=seed + 1, scale=0.5, dtype=BF16)
+    A = a if al == 0 else a.t().contiguous()   # [K, M]
+    Bm = b if bl == 0 else b.t().contiguous()  # [K, N]
+    return a, b, A, Bm
+
+
+def test_gemm_identity_asymmetric(ops):
+    # A = I picks out B^T exactly: catches a transposed or permuted C write
+    M = N = K = 256
+    eye = torch.eye(256, dtype=BF16, device=dev())
+    b = (torch.arange(N, device=dev())[:, None] * 3 + torch.arange(K, device=dev())[None, :] * 0.25 - 40).to(BF16)
+    for al, bl in ((0, 0), (0, 1), (1, 1)):
+        A = eye
+        Bm = b if bl == 0 else b.t().contiguous()
+        c = ops.gemm(A, Bm, a_layout=al, b_layout=bl, M=M, N=N, K=K)
+        assert torch.equal(c, b.t().contiguous()), (al, bl, (c.float() - b.t().float()).abs().max())
+
+
+@pytest.mark.parametrize("al,bl", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 768), (300, 128, 192), (1000, 2304, 768), (24, 384, 128),
+                                   (768, 768, 1000), (128, 256, 65)])
+def test_gemm_layouts_and_tails(ops, al, bl, M, N, K):
+    if K % 8 and (al == 0 or bl == 0):
+        pytest.skip("K-major operands need K % 8 == 0")
+    if al == 1 and M % 8:
+        pytest.skip("M-major A needs M % 8 == 0")
+    a, b, A, Bm = _mk(M, N, K, al, bl, 11)
+    ref = a.float() @ b.float().t()
+    c = ops.gemm(A, Bm, a_layout=al, b_layout=bl, M=M, N=N, K=K)
+    report(f"gemm {al}{bl} {M}x{N}x{K}", c, ref, 0.02 * math.sqrt(K) * 0.25 + 1e-2, 8e-3)
+
+
+def test_gemm_epilogues(ops):
+    M, N, K = 520, 768, 256
+    a, b, A, Bm = _mk(M, N, K, 0, 0, 21)
+    bias = rnd(N, seed=30)
+    aux = rnd(M, N, seed=31, dtype=BF16)
+    acc = a.float() @ b.float().t()
+    report("bias", ops.gemm(A, Bm, epilogue="bias", bias=bias), acc + bias, 5e-2, 8e-3)
+    u, h = ops.gemm(A, Bm, epilogue="bias_gelu", bias=bias)
+    report("u", u, acc + bias, 5e-2, 8e-3)
+    report("gelu(u)", h, torch.nn.functional.gelu(u.float()), 1e-2, 8e-3)
+    x = aux.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    report("dgelu", ops.gemm(A, Bm, epilogue="dgelu", aux=aux), acc.to(BF16).float() * x.grad, 5e-2, 1e-2)
+    report("add", ops.gemm(A, Bm, epilogue="add", aux=aux), acc.to(BF16).float() + aux.float(), 5e-2, 8e-3)
+
+
+def test_gemm_splitk_weight_gradient(ops):
+    # dW[N',K'] = dY^T X, reduction over 3000 tokens, split 7 ways, then the slab reduction
+    Mtok, No, Ko = 3000, 768, 384
+    dy, xx = rnd(Mtok, No, seed=41, scale=0.5, dtype=BF16), rnd(Mtok, Ko, seed=42, scale=0.5, dtype=BF16)
+    slabs = ops.gemm(dy, xx, a_layout=1, b_layout=1, epilogue="f32", M=No, N=Ko, K=Mtok, splitk=7)
+    dst = torch.ones(No, Ko, device=dev())
+    ops.reduce_slabs(slabs, dst, True)
+    ref = dy.float().t() @ xx.float() + 1.0
+    report("dW", dst, ref, 2e-3 * math.sqrt(Mtok), 1e-4)
+    ops.reduce_slabs(slabs, dst, False)
+    report("dW overwrite", dst, ref - 1.0, 2e-3 * math.sqrt(Mtok), 1e-4)
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+def _attn_ref(qkv, mask, B, S, nh, keep=None, p=0.0):
+    H = nh * 64
+    x = qkv.float().view(B, S, 3, nh, 64)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))  # [B,nh,S,64]
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    s = s.masked_fill(~mask[:, None, None, :], torch.finfo(torch.float32).min)
+    pr = torch.softmax(s, dim=-1)
+    if keep is not None:
+        pr = pr * keep / (1 - p)
+    return (pr @ v).transpose(1, 2).reshape(B * S, H)
+
+
+@pytest.mark.parametrize("B,S,nh,lengths", [(2, 256, 12, [256, 130]), (5, 24, 2, [24, 17, 1, 9, 24]),
+                                            (3, 100, 4, [100, 64, 33]), (2, 320, 2, [320, 200])])
+def test_attention_fwd_bwd(ops, B, S, nh, lengths):
+    H = nh * 64
+    qkv = rnd(B * S, 3 * H, seed=1, scale=1.0, dtype=BF16)
+    mask = torch.zeros(B, S, dtype=torch.bool, device=dev())
+    for b, n in enumerate(lengths):
+        mask[b, :n] = True
+    ctx, lse = ops.attention_forward(qkv, mask, B, S, nh)
+    qv = qkv.float().requires_grad_(True)
+    ref = _attn_ref(qv, mask, B, S, nh)
+    report("attn fwd", ctx, ref, 2e-2, 1e-2)
+    dctx = rnd(B * S, H, seed=2, dtype=BF16)
+    ref.backward(dctx.float())
+    dqkv = ops.attention_backward(qkv, mask, ctx, dctx, lse, B, S, nh)
+    g = qv.grad.view(B, S, 3, H)
+    d = dqkv.float().view(B, S, 3, H)
+    # gradients of K/V rows at padded positions are exactly zero in both
+    report("attn dQ", d[:, :, 0], g[:, :, 0], 3e-2, 2e-2)
+    report("attn dK", d[:, :, 1], g[:, :, 1], 3e-2, 2e-2)
+    report("attn dV", d[:, :, 2], g[:, :, 2], 3e-2, 2e-2)
+
+
+def test_attention_dropout_matches_masked_reference(ops):
+    from tests.dropout_ref import keep_mask
+    B, S, nh, p, seed, site = 2, 128, 2, 0.1, 7, 16
+    H = nh * 64
+    qkv = rnd(B * S, 3 * H, seed=3, dtype=BF16)
+    mask = torch.ones(B, S, dtype=torch.bool, device=dev())
+    mask[1, 90:] = False
+    keep = torch.from_numpy(keep_mask(seed, site, p, B * nh * S * S).reshape(B, nh, S, S)).to(dev()).float()
+    ctx, lse = ops.attention_forward(qkv, mask, B, S, nh, p, seed, site)
+    qv = qkv.float().requires_grad_(True)
+    ref = _attn_ref(qv, mask, B, S, nh, keep, p)
+    report("attn+dropout fwd", ctx, ref, 2e-2, 1e-2)
+    dctx = rnd(B * S, H, seed=4, dtype=BF16)
+    ref.backward(dctx.float())
+    dqkv = ops.attention_backward(qkv, mask, ctx, dctx, lse, B, S, nh, p, seed, site)
+    report("attn+dropout dqkv", dqkv, qv.grad, 3e-2, 2e-2)
+
+
+# ------------------------------------------------------------------------------------------------
+# InfoNCE head
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,C,K,T,ls", [(8, 768, 512, 0.05, 0.0), (8, 768, 512, 0.05, 0.1), (256, 768, 4096, 0.05, 0.0),
+                                        (24, 128, 1024, 1.0, 0.0)])
+def test_infonce_head(ops, B, C, K, T, ls):
+    q = rnd(B, C, seed=1, scale=0.4)
+    k = rnd(B, C, seed=2, scale=0.4)
+    k[: B // 2] = q[: B // 2] * 0.9 + 0.02
+    queue = (torch.nn.functional.normalize(rnd(C, K, seed=3), dim=0) * 2.0).contiguous()
+    qb = torch.empty(K, C, dtype=BF16, device=dev())
+    ops.queue_import(queue, qb)
+    ws = ops.infonce_workspace(B, C, K, dev())
+    lse, stats = ops.infonce_forward(q, k, qb, T, ls, ws)
+    # reference on the bf16-rounded operands the MFMA sees; the positive logit stays fp32
+    qq = q.clone().requires_grad_(True)
+    l_pos = (qq * k).sum(1, keepdim=True)
+    q16 = qq + (qq.to(BF16).float() - qq).detach()  # straight-through bf16 rounding
+    l_neg = q16 @ qb.float().t()
+    logits = torch.cat([l_pos, l_neg], 1) / T
+    loss = torch.nn.functional.cross_entropy(logits, torch.zeros(B, dtype=torch.long, device=dev()), label_smoothing=ls)
+    loss.backward()
+    assert abs(float(stats[0]) - float(loss)) < 2e-3 * max(1.0, abs(float(loss))), (float(stats[0]), float(loss))
+    acc = 100 * (logits.argmax(-1) == 0).float().mean()
+    assert abs(float(stats[1]) - float(acc)) < 1e-4
+    assert abs(float(stats[2]) - float(torch.std(q, dim=0).mean())) < 1e-5
+    assert abs(float(stats[3]) - float(torch.std(k, dim=0).mean())) < 1e-5
+    report("lse", lse, torch.logsumexp(logits, 1), 2e-3, 1e-4)
+    dq = ops.infonce_backward(q, k, qb, T, ls, lse, 1.0, ws)
+    report("dq", dq, qq.grad, 2e-2 * float(qq.grad.abs().max()), 2e-2)
