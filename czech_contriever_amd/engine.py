@@ -1,0 +1,319 @@
+"""Host-side engine: flat parameter storage with HF BERT names on top, autograd glue, workspaces.
+
+The encoder keeps ALL parameters in one fp32 device array (layout: include/czc.h) so that the
+momentum EMA, AdamW, the bf16 mirror refresh and the gradient all-reduce are each ONE pass over
+contiguous memory.  `state_dict()` still shows the HF BertModel names/shapes the reference's
+checkpoints use: every named parameter is a VIEW into the flat array.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import lib as L
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+# ----------------------------------------------------------------------------------------------
+# HF name <-> flat offset
+# ----------------------------------------------------------------------------------------------
+def hf_param_table(shape: L.BertShape) -> List[Tuple[str, Tuple[int, ...], int]]:
+    """[(hf_name, shape, flat_offset)] in HF BertModel(add_pooling_layer=False).parameters() order."""
+    lib = L.load()
+    H, I = shape.hidden_size, shape.intermediate_size
+    sp = C.byref(shape)
+    off = lambda kind, l=0: int(lib.czc_param_offset(sp, L.P[kind], l))
+    t = [
+        ("embeddings.word_embeddings.weight", (shape.vocab_size, H), off("WORD")),
+        ("embeddings.position_embeddings.weight", (shape.max_position, H), off("POS")),
+        ("embeddings.token_type_embeddings.weight", (shape.type_vocab_size, H), off("TYPE")),
+        ("embeddings.LayerNorm.weight", (H,), off("ELNW")),
+        ("embeddings.LayerNorm.bias", (H,), off("ELNB")),
+    ]
+    for l in range(shape.num_layers):
+        p = f"encoder.layer.{l}."
+        wqkv, bqkv = off("WQKV", l), off("BQKV", l)
+        t += [
+            (p + "attention.self.query.weight", (H, H), wqkv),
+            (p + "attention.self.query.bias", (H,), bqkv),
+            (p + "attention.self.key.weight", (H, H), wqkv + H * H),
+            (p + "attention.self.key.bias", (H,), bqkv + H),
+            (p + "attention.self.value.weight", (H, H), wqkv + 2 * H * H),
+            (p + "attention.self.value.bias", (H,), bqkv + 2 * H),
+            (p + "attention.output.dense.weight", (H, H), off("WO", l)),
+            (p + "attention.output.dense.bias", (H,), off("BO", l)),
+            (p + "attention.output.LayerNorm.weight", (H,), off("LN1W", l)),
+            (p + "attention.output.LayerNorm.bias", (H,), off("LN1B", l)),
+            (p + "intermediate.dense.weight", (I, H), off("W1", l)),
+            (p + "intermediate.dense.bias", (I,), off("B1", l)),
+            (p + "output.dense.weight", (H, I), off("W2", l)),
+            (p + "output.dense.bias", (H,), off("B2", l)),
+            (p + "output.LayerNorm.weight", (H,), off("LN2W", l)),
+            (p + "output.LayerNorm.bias", (H,), off("LN2B", l)),
+        ]
+    return t
+
+
+class _Node(nn.Module):
+    """A bare container so that parameters can sit under HF's dotted module paths."""
+
+
+def _numel(shape):
+    n = 1
+    for s in shape:
+        n *= s
+    return n
+
+
+class FlatBertEncoder(nn.Module):
+    """BERT encoder + pooling whose arithmetic runs in libczc.so.  Subclassed by src.contriever.Contriever."""
+
+    def __init__(self, config, pooling: str = "average"):
+        super().__init__()
+        self.config = config
+        if not hasattr(config, "pooling"):
+            self.config.pooling = pooling
+        self._shape = L.shape_struct(config)
+        lib = L.load()
+        sp = C.byref(self._shape)
+        self._n = int(lib.czc_param_count(sp))
+        self._n_mat = int(lib.czc_matrix_count(sp))
+        if self._n <= 0:
+            raise RuntimeError("libczc: bad encoder shape")
+        if config.hidden_size % 64 or config.hidden_size != config.num_attention_heads * 64:
+            raise RuntimeError("libczc builds head_dim 64 only (hidden_size = 64 * num_attention_heads)")
+        if getattr(config, "hidden_act", "gelu") != "gelu":
+            raise RuntimeError("libczc builds the erf-GELU ('gelu') activation only")
+        self._table = hf_param_table(self._shape)
+        self._flat = torch.zeros(self._n, dtype=F32)
+        self._flat_grad = None
+        self._mirror = None
+        self._mirror_version = -1
+        self._ws: Dict[tuple, torch.Tensor] = {}
+        self._scratch = None
+        self._call = 0
+        self._anchor = None
+        self._plist: List[nn.Parameter] = []
+        for name, shape, off in self._table:
+            node = self
+            parts = name.split(".")
+            for part in parts[:-1]:
+                if part not in node._modules:
+                    node.add_module(part, _Node())
+                node = node._modules[part]
+            prm = nn.Parameter(self._flat[off:off + _numel(shape)].view(shape))
+            node.register_parameter(parts[-1], prm)
+            self._plist.append(prm)
+        self.reset_parameters()
+
+    # ---- initialisation: HF BertPreTrainedModel._init_weights (N(0, initializer_range); LN = 1, 0) ----
+    def reset_parameters(self):
+        std = float(getattr(self.config, "initializer_range", 0.02))
+        with torch.no_grad():
+            for (name, shape, off), p in zip(self._table, self._plist):
+                if "LayerNorm.weight" in name:
+                    p.fill_(1.0)
+                elif name.endswith(".bias"):
+                    p.zero_()
+                else:
+                    p.normal_(mean=0.0, std=std)
+
+    # ---- storage management ----------------------------------------------------------------------
+    def _rebind(self):
+        for (name, shape, off), p in zip(self._table, self._plist):
+            p.data = self._flat[off:off + _numel(shape)].view(shape)
+            if p.grad is not None:
+                p.grad = None if self._flat_grad is None else self._flat_grad[off:off + _numel(shape)].view(shape)
+
+    def _apply(self, fn, recurse=True):
+        new = fn(self._flat)
+        if new.dtype != F32:
+            raise RuntimeError("the MI355X encoder keeps fp32 master weights (bf16 is the compute mirror): dtype casts are refused")
+        if new is not self._flat:
+            moved = new.device != self._flat.device
+            self._flat = new.contiguous()
+            if moved:
+                self._flat_grad = None
+                self._mirror = None
+                self._ws.clear()
+                self._scratch = None
+                self._anchor = None
+            self._mirror_version = -1
+            self._rebind()
+        return self
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__(copy.deepcopy(self.config, memo))
+        new.to(self._flat.device)
+        with torch.no_grad():
+            new._flat.copy_(self._flat)
+        for p_new, p_old in zip(new._plist, self._plist):
+            p_new.requires_grad = p_old.requires_grad
+        new.train(self.training)
+        memo[id(self)] = new
+        return new
+
+    @property
+    def flat_params(self) -> torch.Tensor:
+        return self._flat
+
+    @property
+    def device(self):
+        return self._flat.device
+
+    def flat_grads(self, create=True):
+        if self._flat_grad is None and create:
+            self._flat_grad = torch.zeros_like(self._flat)
+        return self._flat_grad
+
+    def mirror(self) -> torch.Tensor:
+        """bf16 copy of the matrix region, refreshed when the fp32 array was written by torch."""
+        if not self._flat.is_cuda:
+            raise RuntimeError("libczc has no CPU path: move the model to the GPU (model.cuda()) first")
+        if self._mirror is None:
+            self._mirror = torch.empty(self._n_mat, dtype=BF16, device=self._flat.device)
+            self._mirror_version = -1
+        if self._mirror_version != self._flat._version:
+            L.check(L.load().czc_cast_bf16(self._flat.data_ptr(), self._mirror.data_ptr(), self._n_mat, L.stream_ptr()))
+            self._mirror_version = self._flat._version
+        return self._mirror
+
+    def mark_mirror_fresh(self):
+        self._mirror_version = self._flat._version
+
+    def _workspace(self, B, S, save):
+        key = (B, S, int(save))
+        ws = self._ws.get(key)
+        if ws is None:
+            n = int(L.load().czc_encoder_workspace_bytes(C.byref(self._shape), B, S, int(save)))
+            # keep at most one workspace per kind
+            for k in [k for k in self._ws if k[2] == int(save)]:
+                del self._ws[k]
+            ws = torch.empty(n, dtype=torch.uint8, device=self._flat.device)
+            self._ws[key] = ws
+        return ws
+
+    def _bwd_scratch(self, B, S):
+        n = int(L.load().czc_encoder_backward_scratch_bytes(C.byref(self._shape), B, S))
+        if self._scratch is None or self._scratch.numel() < n:
+            self._scratch = torch.empty(n, dtype=torch.uint8, device=self._flat.device)
+        return self._scratch
+
+    def _pool_code(self):
+        p = getattr(self.config, "pooling", "average")
+        if p == "average":
+            return 0
+        if p == "cls":
+            return 1
+        raise ValueError(f"unknown pooling {p!r}")
+
+    def _shape_for(self, training):
+        return self._shape
+
+    # ---- compute -----------------------------------------------------------------------------------
+    def encode(self, input_ids, attention_mask, normalize=False):
+        if input_ids.dim() != 2:
+            raise ValueError("input_ids must be [batch, seq]")
+        if not input_ids.is_cuda:
+            raise RuntimeError("libczc has no CPU path: inputs must be on the GPU")
+        ids = input_ids.to(torch.int64).contiguous()
+        mask = attention_mask.to(torch.bool).contiguous()
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._plist)
+        if need_grad:
+            if self._anchor is None or self._anchor.device != self._flat.device:
+                self._anchor = torch.zeros(1, device=self._flat.device, requires_grad=True)
+            return _EncoderFn.apply(self._anchor, self, ids, mask, bool(normalize))
+        return self._forward_impl(ids, mask, bool(normalize), save=False)[0]
+
+    def _forward_impl(self, ids, mask, normalize, save):
+        B, S = ids.shape
+        ws = self._workspace(B, S, save)
+        emb = torch.empty(B, self.config.hidden_size, dtype=F32, device=ids.device)
+        self._call += 1
+        seed = (torch.initial_seed() * 2654435761 + self._call * 40503 + id(self) % 9973) & 0xFFFFFFFF
+        L.check(L.load().czc_encoder_forward(
+            C.byref(self._shape), self._flat.data_ptr(), self.mirror().data_ptr(), ids.data_ptr(), mask.data_ptr(),
+            B, S, self._pool_code(), int(normalize), int(self.training), seed, int(save), ws.data_ptr(), ws.numel(),
+            emb.data_ptr(), L.stream_ptr()))
+        return emb, seed, ws
+
+    def _backward_impl(self, ids, mask, normalize, seed, ws, d_emb, training):
+        B, S = ids.shape
+        sc = self._bwd_scratch(B, S)
+        fresh = any(p.grad is None for p in self._plist if p.requires_grad)
+        g = self.flat_grads()
+        L.check(L.load().czc_encoder_backward(
+            C.byref(self._shape), self._flat.data_ptr(), self.mirror().data_ptr(), ids.data_ptr(), mask.data_ptr(),
+            B, S, self._pool_code(), int(normalize), int(training), seed, ws.data_ptr(), ws.numel(), sc.data_ptr(),
+            sc.numel(), d_emb.contiguous().data_ptr(), g.data_ptr(), 0 if fresh else 1, L.stream_ptr()))
+        if fresh:
+            for (name, shape, off), p in zip(self._table, self._plist):
+                if p.requires_grad:
+                    p.grad = g[off:off + _numel(shape)].view(shape)
+
+
+class _EncoderFn(torch.autograd.Function):
+    """emb = encoder(ids, mask); backward writes parameter gradients straight into the flat grad array."""
+
+    @staticmethod
+    def forward(ctx, anchor, enc: FlatBertEncoder, ids, mask, normalize):
+        emb, seed, ws = enc._forward_impl(ids, mask, normalize, save=True)
+        ctx.enc, ctx.ids, ctx.mask, ctx.normalize, ctx.seed, ctx.ws = enc, ids, mask, normalize, seed, ws
+        ctx.training = enc.training
+        ctx.stamp = enc._call
+        return emb
+
+    @staticmethod
+    def backward(ctx, d_emb):
+        enc = ctx.enc
+        if ctx.stamp != enc._call and enc._ws.get((ctx.ids.shape[0], ctx.ids.shape[1], 1)) is ctx.ws:
+            # a later forward of the same shape has reused the activation workspace
+            raise RuntimeError("encoder backward after a newer forward of the same shape: activations were overwritten")
+        enc._backward_impl(ctx.ids, ctx.mask, ctx.normalize, ctx.seed, ctx.ws, d_emb.to(F32), ctx.training)
+        return torch.zeros_like(d_emb[:1, 0]), None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# InfoNCE head (autograd wrapper over czc_infonce_forward / _backward)
+# ----------------------------------------------------------------------------------------------
+class _InfoNCEFn(torch.autograd.Function):
+    """loss = CE([q.k | q.queue] / T, 0).  When q needs a gradient, dq is computed HERE, in the forward,
+    while the queue still holds the negatives the loss was computed on: the reference differentiates
+    through `queue.clone()` (src/moco.py:291), and MoCo.forward overwrites queue rows with this step's
+    keys right after the loss, long before train.py calls backward()."""
+
+    @staticmethod
+    def forward(ctx, q, k, queue_bf16, temperature, label_smoothing, ws, stats_out, want_grad):
+        lib = L.load()
+        B, Cdim = q.shape
+        K = queue_bf16.shape[0]
+        qc, kc = q.contiguous(), k.contiguous()
+        lse = torch.empty(B, dtype=F32, device=q.device)
+        L.check(lib.czc_infonce_forward(qc.data_ptr(), kc.data_ptr(), queue_bf16.data_ptr(), B, Cdim, K,
+                                        float(temperature), float(label_smoothing), ws.data_ptr(), ws.numel(),
+                                        lse.data_ptr(), stats_out.data_ptr(), L.stream_ptr()))
+        if want_grad:
+            dq = torch.empty_like(qc)
+            L.check(lib.czc_infonce_backward(qc.data_ptr(), kc.data_ptr(), queue_bf16.data_ptr(), B, Cdim, K,
+                                             float(temperature), float(label_smoothing), lse.data_ptr(), 1.0,
+                                             ws.data_ptr(), ws.numel(), dq.data_ptr(), L.stream_ptr()))
+            ctx.save_for_backward(dq)
+        ctx.want_grad = want_grad
+        return stats_out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        if not ctx.want_grad:
+            return (None,) * 8
+        (dq,) = ctx.saved_tensors
+        return dq * g, None, None, None, None, None, None, None
+
+
+def infonce_loss(q, k, queue_bf16, temperature, label_smoothing, ws, stats_out):
+    want = bool(torch.is_grad_enabled() and q.requires_grad)
+    return _InfoNCEFn.apply(q, k, queue_bf16, temperature, label_smoothing, ws, stats_out, want)

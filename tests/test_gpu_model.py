@@ -1,0 +1,222 @@
+"""GPU parity of the assembled path (encoder forward / backward, MoCo step) through the drop-in
+Python surface (src.contriever.Contriever, src.moco.MoCo) -> C ABI -> HIP, against
+  (a) golden vectors captured from the reference (tests/golden, made by oracle/make_golden.py), and
+  (b) the CPU oracle on the same seeded inputs at sizes it finishes in seconds.
+Tolerance for pooled embeddings is the north-star bar: cosine >= 1 - 1e-3 per row (bf16 compute
+vs the fp32 reference); absolute tolerances are written at each check."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import moco_bert_oracle as O  # the checker, never the product
+from oracle.make_golden import BASE1, TINY, ragged_batch
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def t(x):
+    return torch.from_numpy(np.asarray(x))
+
+
+def make_encoder(shape_kw, seed, pooling, gpu):
+    from src.contriever import Contriever, bert_config
+    cfg_o = O.BertShape(**shape_kw)
+    cfg = bert_config(vocab_size=cfg_o.vocab_size, hidden_size=cfg_o.hidden_size, num_hidden_layers=cfg_o.num_hidden_layers,
+                      num_attention_heads=cfg_o.num_attention_heads, intermediate_size=cfg_o.intermediate_size,
+                      max_position_embeddings=cfg_o.max_position_embeddings)
+    enc = Contriever(cfg, pooling=pooling)
+    P = O.make_params(cfg_o, seed)
+    missing = enc.load_state_dict(P, strict=True)
+    enc = enc.cuda()
+    return enc, P, cfg_o
+
+
+def cos_rows(a, b):
+    return torch.nn.functional.cosine_similarity(a.double(), b.double(), dim=-1)
+
+
+@pytest.mark.parametrize("name,shape_kw", [("g1_tiny_encoder.npz", TINY), ("g2_base_layer_s64.npz", BASE1),
+                                           ("g2_base_layer_s256.npz", BASE1)])
+def test_encoder_forward_vs_reference_golden(golden_dir, gpu, name, shape_kw):
+    g = load(golden_dir, name)
+    ids, mask = t(g["ids"]).to(gpu), t(g["mask"]).to(gpu)
+    for pooling in ("average", "cls"):
+        enc, _, _ = make_encoder(shape_kw, int(g["seed"]), pooling, gpu)
+        enc.eval()
+        for norm in (0, 1):
+            with torch.no_grad():
+                emb = enc(input_ids=ids, attention_mask=mask, normalize=bool(norm)).cpu()
+            ref = t(g[f"emb_{pooling}_{norm}"])
+            c = cos_rows(emb, ref)
+            assert float(c.min()) >= 1 - 1e-3, (pooling, norm, c)
+            scale = float(ref.abs().max())
+            assert float((emb - ref).abs().max()) <= 3e-2 * scale, (pooling, norm, float((emb - ref).abs().max()), scale)
+
+
+def test_encoder_state_dict_roundtrip_names(gpu):
+    enc, P, cfg_o = make_encoder(TINY, 5, "average", gpu)
+    sd = enc.state_dict()
+    assert list(sd.keys()) == [n for n, _ in O.param_names(cfg_o)]
+    for n, v in P.items():
+        assert torch.equal(sd[n].cpu(), v), n
+
+
+def test_encoder_backward_vs_reference_golden(golden_dir, gpu):
+    g = load(golden_dir, "g7_tiny_grads.npz")
+    ids, mask, cot = t(g["ids"]).to(gpu), t(g["mask"]).to(gpu), t(g["cot"]).to(gpu)
+    for pooling, norm in (("average", False), ("average", True), ("cls", False)):
+        enc, _, cfg_o = make_encoder(TINY, int(g["seed"]), pooling, gpu)
+        enc.eval()  # dropout off, gradients on
+        emb = enc(input_ids=ids, attention_mask=mask, normalize=norm)
+        (emb * cot).sum().backward()
+        tag = f"{pooling}_{int(norm)}"
+        worst = []
+        gmax = max(float(t(g[f"grad_{tag}::{n}"]).abs().max()) for n, _ in enc.named_parameters())
+        for n, p in enc.named_parameters():
+            ref = t(g[f"grad_{tag}::{n}"])
+            got = p.grad.cpu()
+            # key.bias has an exactly-zero gradient (softmax is shift invariant): floor the scale at
+            # 1 % of the largest gradient in the model so that bf16 noise around 0 is not "relative error"
+            scale = max(1e-2 * gmax, float(ref.abs().max()))
+            err = float((got - ref).abs().max()) / scale
+            worst.append((err, n))
+            # bf16 activations and bf16 dY/X operands: 4 % of the tensor's largest gradient
+            assert err <= 4e-2, (tag, n, err, scale)
+        c = torch.nn.functional.cosine_similarity(
+            torch.cat([p.grad.reshape(-1) for p in enc.parameters()]).cpu().double(),
+            torch.cat([t(g[f"grad_{tag}::{n}"]).reshape(-1) for n, _ in enc.named_parameters()]).double(), dim=0)
+        assert float(c) >= 1 - 2e-3, (tag, float(c), sorted(worst)[-3:])
+
+
+def test_encoder_gradient_accumulates_and_zero_grad(gpu):
+    enc, _, _ = make_encoder(TINY, 3, "average", gpu)
+    enc.eval()
+    ids, mask = ragged_batch(4, 16, 1, 512, [16, 9, 3, 16])
+    ids, mask = ids.to(gpu), mask.to(gpu)
+    enc(input_ids=ids, attention_mask=mask).sum().backward()
+    g1 = enc.flat_grads().clone()
+    enc(input_ids=ids, attention_mask=mask).sum().backward()
+    assert torch.allclose(enc.flat_grads(), 2 * g1, rtol=1e-3, atol=1e-5)
+    enc.zero_grad()
+    enc(input_ids=ids, attention_mask=mask).sum().backward()
+    assert torch.allclose(enc.flat_grads(), g1, rtol=1e-3, atol=1e-5)
+
+
+def test_bert_base_full_depth_vs_oracle(gpu):
+    """12-layer bert-base-shaped encoder (small vocab), B=8, S=256 ragged: HIP bf16 vs CPU-oracle fp32."""
+    shape_kw = dict(vocab_size=2048, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                    intermediate_size=3072, max_position_embeddings=512)
+    enc, P, cfg_o = make_encoder(shape_kw, 77, "average", gpu)
+    enc.eval()
+    ids, mask = ragged_batch(8, 256, 78, 2048, [256, 130, 27, 256, 77, 200, 1, 64])
+    with torch.no_grad():
+        ref = O.encoder_forward(P, ids, mask, cfg_o, "average", False)
+        emb = enc(input_ids=ids.to(gpu), attention_mask=mask.to(gpu)).cpu()
+    c = cos_rows(emb, ref)
+    assert float(c.min()) >= 1 - 1e-3, c
+
+
+def _moco_opt(model_dir, **kw):
+    d = dict(queue_size=64, momentum=0.99, temperature=0.05, label_smoothing=0.0, norm_doc=False, norm_query=False,
+             moco_train_mode_encoder_k=False, weight_decay=0.01, weight_decay_from_init=False,
+             retriever_model_id=model_dir, pooling="average", random_init=True, projection_size=128,
+             optim="adamw", lr=1e-3, beta1=0.9, beta2=0.98, eps=1e-6, warmup_steps=2, total_steps=10,
+             lr_min_ratio=0.0, scheduler="linear")
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def _write_cfg(tmp_path, shape_kw, **extra):
+    d = dict(shape_kw)
+    d.update(extra)
+    os.makedirs(tmp_path, exist_ok=True)
+    with open(os.path.join(tmp_path, "config.json"), "w") as f:
+        json.dump(d, f)
+    return str(tmp_path)
+
+
+def test_moco_micro_steps_vs_reference_trace(golden_dir, gpu, tmp_path):
+    """5 full micro-steps (q fwd/bwd, EMA, k fwd, InfoNCE, enqueue, AdamW + warm-up schedule), dropout off,
+    against the trace the reference's own pieces produced (g8)."""
+    from src import moco, utils
+    g = load(golden_dir, "g8_moco_trace.npz")
+    mdir = _write_cfg(tmp_path / "tiny", TINY, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    opt = _moco_opt(mdir)
+    model = moco.MoCo(opt)
+    cfg_o = O.BertShape(**TINY)
+    P = O.make_params(cfg_o, 71)
+    model.encoder_q.load_state_dict(P)
+    model.encoder_k.load_state_dict(P)
+    with torch.no_grad():
+        model.queue.copy_(torch.nn.functional.normalize(O.det_uniform((128, 64), 72), dim=0))
+    model = model.cuda()
+    model.train()
+    optimizer, scheduler = utils.set_optim(opt, model)
+    B, S = 8, 24
+    for step in range(5):
+        q_tokens, q_mask = ragged_batch(B, S, 7300 + step, 512, [S, 17, 3, 24, 9, 24, 12, 20])
+        k_tokens, k_mask = ragged_batch(B, S, 7400 + step, 512, [20, S, 5, 11, 24, 7, 24, 16])
+        loss, stats = model(q_tokens.to(gpu), q_mask.to(gpu), k_tokens.to(gpu), k_mask.to(gpu), stats_prefix="train")
+        loss.backward()
+        optimizer.step()
+        scheduler.step()
+        model.zero_grad()
+        ref_loss = float(g["losses"][step])
+        # logits are O(10) with T = 0.05: bf16 q / queue / encoder give ~1e-2 absolute on the loss
+        assert abs(float(loss) - ref_loss) < 3e-2 * max(1.0, abs(ref_loss)), (step, float(loss), ref_loss)
+        assert int(model.queue_ptr) == int(g["ptrs"][step])
+        assert abs(float(stats["train/stdq"][0]) - float(g["stdq"][step])) < 5e-3
+        assert abs(float(stats["train/stdk"][0]) - float(g["stdk"][step])) < 5e-3
+    qf = model.queue.cpu()
+    assert float((qf - t(g["queue_final"])).abs().max()) < 2e-2
+    wq = model.encoder_q.state_dict()["encoder.layer.1.output.dense.weight"].cpu()[::7, ::5]
+    wk = model.encoder_k.state_dict()["encoder.layer.1.output.dense.weight"].cpu()[::7, ::5]
+    # AdamW's first steps move every weight by ~lr regardless of gradient size; sign flips of tiny bf16
+    # gradients show up as 2*lr differences
+    assert float((wq - t(g["wq_probe"])).abs().max()) < 4e-3
+    assert float((wk - t(g["wk_probe"])).abs().max()) < 1e-4
+
+
+def test_moco_checkpoint_layout_roundtrip(gpu, tmp_path):
+    from src import moco, utils
+    mdir = _write_cfg(tmp_path / "tiny", TINY)
+    opt = _moco_opt(mdir, output_dir=str(tmp_path / "out"))
+    model = moco.MoCo(opt).cuda()
+    optimizer, scheduler = utils.set_optim(opt, model)
+    ids, mask = ragged_batch(8, 16, 1, 512)
+    loss, _ = model(ids.to(gpu), mask.to(gpu), ids.to(gpu), mask.to(gpu))
+    loss.backward()
+    optimizer.step(); scheduler.step()
+    utils.save(model, optimizer, scheduler, 1, opt, str(tmp_path / "out"), "step-1")
+    latest = tmp_path / "out" / "checkpoint" / "latest"
+    assert os.path.islink(latest)
+    ck = torch.load(latest / "checkpoint.pth", map_location="cpu", weights_only=False)
+    assert sorted(ck.keys()) == ["model", "opt", "optimizer", "scheduler", "step"]
+    keys = list(ck["model"].keys())
+    n_enc = len(O.param_names(O.BertShape(**TINY)))
+    assert keys[:2] == ["queue", "queue_ptr"] and len(keys) == 2 + 2 * n_enc
+    assert tuple(ck["model"]["queue"].shape) == (128, 64) and ck["model"]["queue_ptr"].dtype == torch.int64
+    assert all(k.startswith(("encoder_q.", "encoder_k.")) for k in keys[2:])
+    model2, opt2, sch2, opt_ck, step = utils.load(moco.MoCo, str(latest), opt)
+    assert step == 1
+    for (n1, a), (n2, b) in zip(model.state_dict().items(), model2.state_dict().items()):
+        assert n1 == n2 and torch.equal(a.cpu(), b.cpu()), n1
+    sd1, sd2 = optimizer.state_dict(), opt2.state_dict()
+    assert sd1["param_groups"] == sd2["param_groups"]
+    for k in sd1["state"]:
+        assert torch.equal(sd1["state"][k]["exp_avg"].cpu(), sd2["state"][k]["exp_avg"].cpu())
