@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py — contrastive pairs/sec of the MoCo training micro-step on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one full training micro-step of train.py's loop on one synthetic batch per GPU
+(BASELINE.json config 2/3): query-encoder forward + backward, momentum EMA, key-encoder forward,
+InfoNCE logits + cross-entropy forward/backward against the 131 072-slot queue, key all-gather +
+enqueue, gradient all-reduce, AdamW (update_freq = 1 since target_batch_size = 256 * N).
+bert-base-sized random-init weights (no checkpoints offline), chunk_length 256, per_gpu_batch_size 256,
+T 0.05, momentum 0.9995, dropout 0.1 ON in both encoders as the reference trains.
+Prints ONE JSON line on rank 0 (contract: the task statement; extra objects `roofline`, `cpu_baseline`).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import tempfile
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+FLOP_PER_PAIR = 184.01e9           # 4 x encoder fwd (45.902 G) + head 0.403 G
+
+BERT_BASE = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                 intermediate_size=3072, max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12,
+                 hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, hidden_act="gelu",
+                 initializer_range=0.02)
+
+
+def make_opt(model_dir, batch, world, queue):
+    return types.SimpleNamespace(
+        retriever_model_id=model_dir, random_init=True, pooling="average", projection_size=768,
+        queue_size=queue, momentum=0.9995, temperature=0.05, label_smoothing=0.0,
+        norm_query=False, norm_doc=False, moco_train_mode_encoder_k=False,
+        weight_decay=0.01, weight_decay_from_init=False, optim="adamw", scheduler="linear",
+        lr=1e-5, beta1=0.9, beta2=0.98, eps=1e-6, warmup_steps=20000, total_steps=500000, lr_min_ratio=0.0,
+        per_gpu_batch_size=batch, target_batch_size=batch * world, chunk_length=256, seed=0)
+
+
+def synthetic_batches(rank, batch, seq, n, device):
+    out = []
+    for t in range(n):
+        g = torch.Generator().manual_seed(1234 + 1000 * rank + t)
+        q = torch.randint(1000, 30522, (batch, seq), generator=g, dtype=torch.int64)
+        k = torch.randint(1000, 30522, (batch, seq), generator=g, dtype=torch.int64)
+        m = torch.ones(batch, seq, dtype=torch.bool)
+        out.append(dict(q_tokens=q.to(device), q_mask=m.to(device), k_tokens=k.to(device), k_mask=m.to(device)))
+    return out
+
+
+def cpu_baseline(seq, cpu_batch=8, steps=3):
+    """The CPU oracle (fp32, the reference's arithmetic) timed on this host: identical micro-step,
+    B reduced to 8 (pairs/s is batch-insensitive on CPU).  kind = "port"."""
+    from oracle import moco_bert_oracle as O
+    cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
+    torch.set_num_threads(cores)
+    cfg = O.BertShape()
+    P = O.make_params(cfg, 0)
+    queue = O.init_queue(768, 8192, 0)   # K=8192 slots: the head is 0.2 % of the step either way
+    st = O.MoCoState(cfg, P, queue, momentum=0.9995, temperature=0.05)
+    g = torch.Generator().manual_seed(99)
+    times = []
+    log(f"cpu baseline: oracle built, {cores} threads")
+    for i in range(steps + 1):
+        q = torch.randint(1000, 30522, (cpu_batch, seq), generator=g)
+        k = torch.randint(1000, 30522, (cpu_batch, seq), generator=g)
+        m = torch.ones(cpu_batch, seq, dtype=torch.bool)
+        t0 = time.perf_counter()
+        st.forward_backward(q, m, k, m, training=True)
+        st.optimizer_step(1e-5)
+        times.append(time.perf_counter() - t0)
+        log(f"cpu baseline step {i}: {times[-1]:.2f} s")
+    med = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": round(cpu_batch / med, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} full fp32 micro-steps (1 warm-up) of the CPU oracle at B={cpu_batch}, S={seq}, "
+                      f"bert-base, queue 8192, dropout on; median {med:.2f} s/step"}
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (headline: 256)")
+    ap.add_argument("--seq", type=int, default=256, help="chunk_length (headline: 256)")
+    ap.add_argument("--queue", type=int, default=131072)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropout", action="store_true", help="diagnostic only: the headline keeps dropout on")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from czech_contriever_amd import lib as L
+    from czech_contriever_amd.parallel import DataParallel
+    from src import moco, utils
+    lib = L.load()
+
+    mdir = tempfile.mkdtemp(prefix="czc_bench_")
+    cfg = dict(BERT_BASE)
+    if args.no_dropout:
+        cfg.update(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    with open(os.path.join(mdir, "config.json"), "w") as f:
+        json.dump(cfg, f)
+    opt = make_opt(mdir, args.batch, world, args.queue)
+    torch.manual_seed(opt.seed)
+    model = moco.MoCo(opt).to(device)
+    model.train()
+    optimizer, scheduler = utils.set_optim(opt, model)
+    model = DataParallel(model, optimizer)
+    batches = synthetic_batches(rank, args.batch, args.seq, 16, device)
+    if rank == 0:
+        log(f"model on {device}, {sum(p.numel() for p in model.module.encoder_q.parameters())/1e6:.1f} M params/encoder; warm-up {args.warmup}")
+
+    def step(i):
+        loss, _ = model(**batches[i % len(batches)], stats_prefix="train")
+        loss.backward()
+        optimizer.step()
+        scheduler.step()
+        model.zero_grad()
+        return loss
+
+    for i in range(args.warmup):
+        last = step(i)
+        torch.cuda.synchronize()
+        if rank == 0:
+            log(f"warm-up step {i} done, loss {float(last.detach()):.4f}, mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+    torch.cuda.synchronize()
+    if args.warmup and not torch.isfinite(last.detach()).item():
+        raise SystemExit("non-finite loss in warm-up")
+
+    # dominant kernel = the FFN-up GEMM (bias+GELU epilogue): hipEvents around each of its launches
+    M, N, K = args.batch * args.seq, cfg["intermediate_size"], cfg["hidden_size"]
+    L.check(lib.czc_probe_arm(0, 0, L.EPI["bias_gelu"], M, N, K, 24 * args.steps))
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    tot_ms, cnt = ctypes.c_float(0), ctypes.c_int(0)
+    L.check(lib.czc_probe_read(ctypes.byref(tot_ms), ctypes.byref(cnt)))
+    L.check(lib.czc_probe_arm(0, 0, 0, 0, 0, 0, 0))
+
+    if rank == 0:
+        log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
+        pairs = args.batch * world * args.steps
+        value = pairs / elapsed
+        kern_ms = tot_ms.value / max(1, cnt.value)
+        kern_tflops = (2.0 * M * N * K) / (kern_ms * 1e-3) / 1e12 if cnt.value else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_pmc_ffn_up.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+        headline = (args.batch == 256 and args.seq == 256 and args.queue == 131072 and not args.no_dropout)
+        out = {
+            "metric": "contrastive pairs/sec (seq256, bsz256/GPU, queue131k)",
+            "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "MoCo CZERT (bert-base-sized) bf16, chunk_length=256, per_gpu_batch_size=256, "
+                                   "queue_size=131072, temperature=0.05" if headline else
+                                   f"NON-HEADLINE diagnostic: batch={args.batch} seq={args.seq} queue={args.queue} dropout={not args.no_dropout}",
+                       "global_batch": args.batch * world, "seq_len": args.seq, "queue_size": args.queue,
+                       "parallelism": f"dp{world}", "weights": "random-init bert-base (seed 0)", "dropout": 0.0 if args.no_dropout else 0.1,
+                       "step": "q fwd+bwd, EMA, k fwd, InfoNCE fwd+bwd, all-gather+enqueue, grad all-reduce, AdamW"},
+            "roofline": {"bound": "mfma", "achieved": None if kern_tflops is None else round(kern_tflops, 1),
+                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": None if kern_tflops is None else round(kern_tflops / PEAK_BF16_TFLOPS, 4),
+                         "traffic": traffic,
+                         "kernel": "czc::gemm_kernel<0,0,2> FFN-up x.W1^T + bias -> (u, gelu(u)), "
+                                   f"M={M} N={N} K={K}, {2.0 * M * N * K / 1e9:.1f} GFLOP/launch",
+                         "kernel_ms": round(kern_ms, 4), "launches_timed": cnt.value,
+                         "whole_step_frac": round(value * FLOP_PER_PAIR / (world * PEAK_BF16_TFLOPS * 1e12), 4)},
+            "final_loss": round(float(last.detach()), 4),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.seq)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -329,7 +329,31 @@ static int launch_layout(int al, int bl, const GemmArgs& a, int splits, hipStrea
   return CZC_ERR_INVALID;
 }
 
+// ---- optional timing probe: hipEvents around every launch of ONE (layouts, epilogue, M, N, K) shape ----
+struct Probe {
+  bool armed = false;
+  int al, bl, epi, M, N, K;
+  int max_samples = 0, count = 0;
+  hipEvent_t* ev = nullptr;  // 2 per sample
+};
+static Probe g_probe;
+
+static int gemm_dispatch_inner(int al, int bl, int epi, GemmArgs a, int splitk, hipStream_t st);
+
 int gemm_dispatch(int al, int bl, int epi, GemmArgs a, int splitk, hipStream_t st) {
+  Probe& p = g_probe;
+  const bool hit = p.armed && p.count < p.max_samples && al == p.al && bl == p.bl && epi == p.epi && a.M == p.M &&
+                   a.N == p.N && a.K == p.K;
+  if (hit) CZC_HIP(hipEventRecord(p.ev[2 * p.count], st));
+  const int rc = gemm_dispatch_inner(al, bl, epi, a, splitk, st);
+  if (hit) {
+    CZC_HIP(hipEventRecord(p.ev[2 * p.count + 1], st));
+    ++p.count;
+  }
+  return rc;
+}
+
+static int gemm_dispatch_inner(int al, int bl, int epi, GemmArgs a, int splitk, hipStream_t st) {
   CZC_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "czc_gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
   CZC_REQUIRE((a.lda % 8) == 0 && (a.ldb % 8) == 0 && (a.ldc % 8) == 0,
               "czc_gemm: leading dimensions must be multiples of 8 (lda=%d ldb=%d ldc=%d)", a.lda, a.ldb, a.ldc);
@@ -389,6 +413,39 @@ extern "C" int czc_gemm_bf16(int a_layout, int b_layout, int epilogue, int M, in
   a.A = A; a.B = B; a.C = C; a.C2 = C2; a.bias = bias; a.aux = aux;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   return gemm_dispatch(a_layout, b_layout, epilogue, a, splitk, (hipStream_t)stream);
+}
+
+extern "C" int czc_probe_arm(int a_layout, int b_layout, int epilogue, int M, int N, int K, int max_samples) {
+  Probe& p = g_probe;
+  if (p.ev) {
+    for (int i = 0; i < 2 * p.max_samples; ++i) (void)hipEventDestroy(p.ev[i]);
+    delete[] p.ev;
+    p.ev = nullptr;
+  }
+  p.armed = false;
+  p.count = 0;
+  p.max_samples = 0;
+  if (max_samples <= 0) return CZC_OK;  // disarm
+  p.ev = new hipEvent_t[2 * max_samples];
+  for (int i = 0; i < 2 * max_samples; ++i) CZC_HIP(hipEventCreate(&p.ev[i]));
+  p.al = a_layout; p.bl = b_layout; p.epi = epilogue; p.M = M; p.N = N; p.K = K;
+  p.max_samples = max_samples;
+  p.armed = true;
+  return CZC_OK;
+}
+
+extern "C" int czc_probe_read(float* total_ms, int* count) {
+  Probe& p = g_probe;
+  float tot = 0.f;
+  for (int i = 0; i < p.count; ++i) {
+    float ms = 0.f;
+    CZC_HIP(hipEventSynchronize(p.ev[2 * i + 1]));
+    CZC_HIP(hipEventElapsedTime(&ms, p.ev[2 * i], p.ev[2 * i + 1]));
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (count) *count = p.count;
+  return CZC_OK;
 }
 
 extern "C" int czc_reduce_slabs(const float* slabs, int nslabs, int64_t n, float* dst, int accumulate,

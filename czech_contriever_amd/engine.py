@@ -97,6 +97,7 @@ class FlatBertEncoder(nn.Module):
         self._scratch = None
         self._call = 0
         self._anchor = None
+        self._post_backward = []  # callables(enc) run right after the backward has been enqueued
         self._plist: List[nn.Parameter] = []
         for name, shape, off in self._table:
             node = self
@@ -255,6 +256,8 @@ class FlatBertEncoder(nn.Module):
             for (name, shape, off), p in zip(self._table, self._plist):
                 if p.requires_grad:
                     p.grad = g[off:off + _numel(shape)].view(shape)
+        for hook in self._post_backward:
+            hook(self)
 
 
 class _EncoderFn(torch.autograd.Function):

@@ -1,0 +1,80 @@
+"""Data parallelism for the MoCo path: one process per GPU, RCCL over xGMI (torch.distributed "nccl").
+
+Replaces torch DDP at train.py:483-488 of the reference.  DDP cannot be used here: parameter
+gradients are written by libczc straight into one flat fp32 array, not through autograd hooks.
+What this wrapper does instead, per micro-step:
+  * gradient mean all-reduce of the WHOLE flat gradient array as one collective (435.6 MB fp32 at
+    bert-base), launched on a side stream the moment the encoder backward has been enqueued;
+    the optimizer waits on its event.  (The reference all-reduces on every micro-step as well:
+    it never enters no_sync(), train.py:263-266.)
+  * no buffer broadcast: DDP re-broadcasts `queue` (403 MB) from rank 0 on every forward; the
+    replicas are identical by construction (same gathered keys, same order), so nothing is sent.
+The key all-gather is in src.moco / src.dist_utils."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .engine import FlatBertEncoder
+
+
+def world():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+@torch.no_grad()
+def average_(flat: torch.Tensor, group=None):
+    """In-place mean over ranks of a flat gradient array."""
+    if world() == 1:
+        return flat
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(dist.get_world_size(group))
+    return flat
+
+
+class DataParallel(nn.Module):
+    """`.module` is the wrapped MoCo (same attribute the reference reads from its DDP wrapper)."""
+
+    def __init__(self, module: nn.Module, optimizer=None):
+        super().__init__()
+        self.module = module
+        self._encoders = [m for m in module.modules() if isinstance(m, FlatBertEncoder)
+                          and any(p.requires_grad for p in m._plist)]
+        self._comm = None
+        self._done = None
+        for enc in self._encoders:
+            enc._post_backward = [self._reduce]
+        if optimizer is not None:
+            self.attach(optimizer)
+
+    def attach(self, optimizer):
+        optimizer._pre_step.append(self.wait)
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def _reduce(self, enc):
+        if world() == 1:
+            return
+        g = enc.flat_grads(create=False)
+        if g.is_cuda:
+            if self._comm is None:
+                self._comm = torch.cuda.Stream()
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(self._comm):
+                self._comm.wait_event(ready)
+                average_(g)
+                self._done = torch.cuda.Event()
+                self._done.record()
+        else:
+            average_(g)
+
+    def wait(self):
+        if self._done is not None:
+            torch.cuda.current_stream().wait_event(self._done)
+            self._done = None

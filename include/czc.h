@@ -185,6 +185,12 @@ int czc_gemm_bf16(int a_layout, int b_layout, int epilogue, int M, int N, int K,
                   void* C, int ldc, const float* bias, const uint16_t* aux, void* C2,
                   int splitk, czc_stream_t stream);
 
+/* Timing probe (bench only): records hipEvents on the launch stream around every czc GEMM launch whose
+ * (layouts, epilogue, M, N, K) match, up to max_samples launches; max_samples <= 0 disarms.
+ * czc_probe_read synchronises on the recorded events and returns their summed duration. */
+int czc_probe_arm(int a_layout, int b_layout, int epilogue, int M, int N, int K, int max_samples);
+int czc_probe_read(float* total_ms, int* count);
+
 /* dst (+)= sum_z slabs[z]  (n elements each) */
 int czc_reduce_slabs(const float* slabs, int nslabs, int64_t n, float* dst, int accumulate,
                      czc_stream_t stream);

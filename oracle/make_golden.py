@@ -220,13 +220,13 @@ def g_adamw(ru):
     save("g6_adamw.npz", **out)
 
 
-def g_trace(rc, rm, ru):
+def g_trace(rc, rm, ru, name="g8_moco_trace.npz", norm=False, ls=0.0):
     """5 MoCo micro-steps (update_freq=1), dropout off, tiny encoder: the loss sequence."""
     cfg = O.BertShape(**TINY)
     P = O.make_params(cfg, 71)
     C, K, B, S = cfg.hidden_size, 64, 8, 24
     m = bare_moco(rm)
-    m.momentum, m.temperature, m.label_smoothing = 0.99, 0.05, 0.0
+    m.momentum, m.temperature, m.label_smoothing = 0.99, 0.05, ls
     m.encoder_q = ref_encoder(rc, cfg, P, "average")
     m.encoder_k = ref_encoder(rc, cfg, P, "average")
     for p in m.encoder_k.parameters():
@@ -245,13 +245,13 @@ def g_trace(rc, rm, ru):
         lens_k = [20, S, 5, 11, 24, 7, 24, 16]
         q_tokens, q_mask = ragged_batch(B, S, 7300 + step, cfg.vocab_size, lens_q)
         k_tokens, k_mask = ragged_batch(B, S, 7400 + step, cfg.vocab_size, lens_k)
-        q = m.encoder_q(input_ids=q_tokens, attention_mask=q_mask, normalize=False)
+        q = m.encoder_q(input_ids=q_tokens, attention_mask=q_mask, normalize=norm)
         with torch.no_grad():
             m._momentum_update_key_encoder()
-            k = m.encoder_k(input_ids=k_tokens, attention_mask=k_mask, normalize=False)
+            k = m.encoder_k(input_ids=k_tokens, attention_mask=k_mask, normalize=norm)
         logits = m._compute_logits(q, k) / m.temperature
         labels = torch.zeros(B, dtype=torch.long)
-        loss = torch.nn.functional.cross_entropy(logits, labels, label_smoothing=0.0)
+        loss = torch.nn.functional.cross_entropy(logits, labels, label_smoothing=ls)
         enq(m, k, None)
         loss.backward()
         optimizer.step()
@@ -263,7 +263,7 @@ def g_trace(rc, rm, ru):
         stdks.append(float(torch.std(k, dim=0).mean()))
         ptrs.append(int(m.queue_ptr))
         qs.append(q.detach().clone())
-    save("g8_moco_trace.npz", losses=np.array(losses), accs=np.array(accs), stdq=np.array(stdqs),
+    save(name, losses=np.array(losses), accs=np.array(accs), stdq=np.array(stdqs),
          stdk=np.array(stdks), ptrs=np.array(ptrs), q=torch.stack(qs), queue_final=m.queue,
          wq_probe=m.encoder_q.state_dict()["encoder.layer.1.output.dense.weight"][::7, ::5],
          wk_probe=m.encoder_k.state_dict()["encoder.layer.1.output.dense.weight"][::7, ::5])
@@ -288,6 +288,7 @@ def main():
         "g6": lambda: g_adamw(ru),
         "g7": lambda: g_grads(rc, "g7_tiny_grads.npz", TINY, 11, 5, 24, [24, 17, 1, 9, 24]),
         "g8": lambda: g_trace(rc, rm, ru),
+        "g9": lambda: g_trace(rc, rm, ru, "g9_moco_trace_norm.npz", norm=True, ls=0.1),
     }
     for k, fn in jobs.items():
         if a.only and k not in a.only.split(","):

@@ -323,7 +323,7 @@ class MoCoState:
         acc, stdq, stdk = step_stats(logits.detach(), q.detach(), k)
         return loss.detach(), q.detach(), k, {"accuracy": acc, "stdq": stdq, "stdk": stdk}
 
-    def optimizer_step(self, lr, beta1=0.9, beta2=0.98, eps=1e-6, weight_decay=0.01):
+    def optimizer_step(self, lr, beta1=0.9, beta2=0.98, eps=1e-6, weight_decay=0.01, keep_grads=False):
         self.opt_step += 1
         with torch.no_grad():
             for n, p in self.Pq.items():
@@ -332,4 +332,5 @@ class MoCoState:
                 newp, self.m[n], self.v[n] = adamw_step(
                     p.detach(), p.grad, self.m[n], self.v[n], self.opt_step, lr, beta1, beta2, eps, weight_decay)
                 p.copy_(newp)
-                p.grad = None
+                if not keep_grads:
+                    p.grad = None

@@ -113,13 +113,14 @@ def test_adamw_and_schedule_match_reference(golden_dir):
             assert torch.allclose(p, t(g[f"p_w{warm}"][step]), atol=2e-7, rtol=1e-6)
 
 
-def test_moco_trace_matches_reference(golden_dir):
+@pytest.mark.parametrize("name,norm,ls", [("g8_moco_trace.npz", False, 0.0), ("g9_moco_trace_norm.npz", True, 0.1)])
+def test_moco_trace_matches_reference(golden_dir, name, norm, ls):
     from oracle.make_golden import ragged_batch
-    g = load(golden_dir, "g8_moco_trace.npz")
+    g = load(golden_dir, name)
     cfg = O.BertShape(**TINY)
     P = O.make_params(cfg, 71)
     queue = torch.nn.functional.normalize(O.det_uniform((cfg.hidden_size, 64), 72), dim=0)
-    st = O.MoCoState(cfg, P, queue, momentum=0.99, temperature=0.05)
+    st = O.MoCoState(cfg, P, queue, momentum=0.99, temperature=0.05, label_smoothing=ls, norm_query=norm, norm_doc=norm)
     B, S = 8, 24
     for step in range(5):
         q_tokens, q_mask = ragged_batch(B, S, 7300 + step, cfg.vocab_size, [S, 17, 3, 24, 9, 24, 12, 20])
