@@ -58,12 +58,40 @@ def synthetic_batches(rank, batch, seq, n, device):
     return out
 
 
-def cpu_baseline(seq, cpu_batch=8, steps=3):
+def host_cpu_share():
+    """CPUs this process may actually use: affinity, capped by the cgroup CPU quota (a GPU box gives a
+    one-GPU job a 16-CPU share of a much larger host; spawning one thread per visible core there
+    oversubscribes the quota and stalls OpenMP)."""
+    n = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+            if q != "max":
+                quota = max(1, int(int(q) / int(per)))
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = int(f.read()), int(g.read())
+                if q > 0:
+                    quota = max(1, q // per)
+        except Exception:
+            pass
+    if quota is not None:
+        n = min(n, quota)
+    env = os.environ.get("CZC_CPU_THREADS")
+    if env:
+        return max(1, int(env))
+    return min(n, 16) if quota is None else n
+
+
+def cpu_baseline(seq, cpu_batch=8, steps=2):
     """The CPU oracle (fp32, the reference's arithmetic) timed on this host: identical micro-step,
     B reduced to 8 (pairs/s is batch-insensitive on CPU).  kind = "port"."""
     from oracle import moco_bert_oracle as O
-    cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
+    cores = host_cpu_share()
     torch.set_num_threads(cores)
+    log(f"cpu baseline: {cores} threads (affinity {len(os.sched_getaffinity(0))}, os.cpu_count {os.cpu_count()})")
     cfg = O.BertShape()
     P = O.make_params(cfg, 0)
     queue = O.init_queue(768, 8192, 0)   # K=8192 slots: the head is 0.2 % of the step either way

@@ -1,0 +1,82 @@
+"""N > 1 path on CPU: world_size 2 over gloo (the RCCL calls are the same torch.distributed calls).
+Checks the pieces of the multi-GPU design that do not need a GPU: rank-order key all-gather (so the
+replicated queues stay bit-identical), the autograd all-gather (InBatch-style), flat-gradient averaging,
+and the cross-rank stats reduction."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import moco_bert_oracle as O
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from src import dist_utils, utils
+        from czech_contriever_amd import parallel
+        torch.manual_seed(rank)
+        C, K, B = 16, 64, 4
+        # replicated queue, identical start on every rank
+        queue = torch.nn.functional.normalize(O.det_uniform((C, K), 5), dim=0)
+        ptr = 0
+        for step in range(10):   # 10 * 2 * 4 = 80 > 64: wraps
+            keys = O.det_uniform((B, C), 100 + 10 * step + rank)
+            allk = dist_utils.gather_nograd(keys)
+            assert allk.shape == (world * B, C)
+            for r in range(world):  # rank order
+                assert torch.equal(allk[r * B:(r + 1) * B], O.det_uniform((B, C), 100 + 10 * step + r))
+            queue, ptr = O.enqueue(queue, ptr, allk)
+        digest = queue.double().sum().item()
+        all_digest = [None] * world
+        dist.all_gather_object(all_digest, (digest, ptr))
+        assert all(d == all_digest[0] for d in all_digest), all_digest
+
+        # autograd all-gather: each rank gets the SUM over ranks of the gradient of its slice
+        x = O.det_uniform((B, C), 7 + rank).requires_grad_(True)
+        g = dist_utils.gather(x)
+        w = O.det_uniform((world * B, C), 9)
+        ((g * w).sum() * (rank + 1)).backward()
+        expect = w[rank * B:(rank + 1) * B] * sum(r + 1 for r in range(world))
+        assert torch.allclose(x.grad, expect)
+
+        # flat gradient averaging (what DataParallel launches after the encoder backward)
+        flat = O.det_uniform((1001,), 11 + rank)
+        ref = sum(O.det_uniform((1001,), 11 + r) for r in range(world)) / world
+        parallel.average_(flat)
+        assert torch.allclose(flat, ref, atol=1e-7)
+
+        # stats: weighted mean over ranks lands on rank 0
+        st = utils.WeightedAvgStats()
+        st.update({"train/loss": (float(rank + 1), 4 * (rank + 1))})
+        avg = st.average_stats
+        if rank == 0:
+            assert abs(avg["train/loss"] - (1 * 4 + 2 * 8) / 12) < 1e-6
+        out.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        out.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res

@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""train.py — MoCo contrastive pre-training on MI355X, same command line as the reference.
+
+    torchrun --nproc_per_node=N train.py --retriever_model_id czert --random_init \\
+        --chunk_length 256 --per_gpu_batch_size 256 --target_batch_size 2048 --queue_size 131072 \\
+        --temperature 0.05 --momentum 0.9995 --lr 1e-5 --total_steps 500000 ...
+
+Loop skeleton of Ajchler/czech-contriever train.py:246-327 (accumulate `update_freq` micro-steps,
+log every log_freq, optional clipping, optimizer/scheduler step, zero_grad, periodic save) on the
+libczc.so path.  Differences from the file as committed upstream (SURVEY.md "five facts" #5):
+  * no clearml import at module load; TensorBoard is optional (utils.init_tb_logger)
+  * torch DDP is replaced by czech_contriever_amd.parallel.DataParallel (flat-gradient all-reduce
+    over RCCL, no per-forward 403 MB queue broadcast)
+  * the batch is moved with non_blocking copies; stats stay on the device until log_freq
+  * per-parameter grad norms (197 host syncs) are replaced by ONE squared-norm reduction
+  * data: `--train_data` jsonl files are read by src/data_min.py (tokenise, two random crops, [CLS]/[SEP],
+    pad id 0); with no `--train_data` the loop runs on synthetic token ids (seed 1234 + 1000*rank + step).
+  * BEIR / validation-set evaluation (eval_model, eval_loss) are outside the hot path and not built.
+"""
+import logging
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+from src import dist_utils, moco, utils
+from src.options import Options
+
+logger = logging.getLogger(__name__)
+
+
+class SyntheticPairs:
+    """Endless (q, k) token-id batches of the shape the reference's Collator produces (src/data.py:531-573)."""
+
+    def __init__(self, opt, rank, vocab_size):
+        self.B, self.S, self.rank, self.V = opt.per_gpu_batch_size, opt.chunk_length, rank, vocab_size
+        self.step = 0
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        g = torch.Generator().manual_seed(1234 + 1000 * self.rank + self.step)
+        self.step += 1
+        lo = min(1000, self.V // 2)
+        q = torch.randint(lo, self.V, (self.B, self.S), generator=g, dtype=torch.int64)
+        k = torch.randint(lo, self.V, (self.B, self.S), generator=g, dtype=torch.int64)
+        m = torch.ones(self.B, self.S, dtype=torch.bool)
+        return {"q_tokens": q, "q_mask": m, "k_tokens": k, "k_mask": m.clone()}, None
+
+
+def make_batches(opt, model, rank, world):
+    core = model.module if hasattr(model, "module") else model
+    if opt.train_data:
+        from src import data_min
+        return data_min.loader(opt, core.tokenizer, rank, world)
+    return SyntheticPairs(opt, rank, core.encoder_q.config.vocab_size)
+
+
+def train(opt, model, optimizer, scheduler, step):
+    run_stats = utils.WeightedAvgStats()
+    tb_logger = utils.init_tb_logger(opt.output_dir)
+    rank, world = dist_utils.get_rank(), dist_utils.get_world_size()
+    device = torch.device("cuda", torch.cuda.current_device())
+    batches = make_batches(opt, model, rank, world)
+
+    if opt.target_batch_size % (opt.per_gpu_batch_size * world) != 0:
+        raise ValueError("target_batch_size must be divisible by per_gpu_batch_size * dist.get_world_size()")
+    update_freq = opt.target_batch_size // (opt.per_gpu_batch_size * world)
+
+    model.train()
+    accumulate_steps = 0
+    t_last, step_last = time.time(), step
+    for batch, _ in batches:
+        if step >= opt.total_steps:
+            break
+        accumulate_steps += 1
+        batch = {k: (v.to(device, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+        train_loss, iter_stats = model(**batch, stats_prefix="train")
+        train_loss.backward()
+
+        if accumulate_steps % update_freq != 0:
+            continue
+        run_stats.update(iter_stats)
+        if step % opt.log_freq == 0:
+            log = f"{step} / {opt.total_steps}"
+            for k, v in sorted(run_stats.average_stats.items()):
+                log += f" | {k}: {v:.3f}"
+                if tb_logger:
+                    tb_logger.add_scalar(k, v, step)
+            lr = scheduler.get_last_lr()[0]
+            log += f" | lr: {lr:0.3g}"
+            log += f" | Memory: {torch.cuda.max_memory_allocated() // 1e9} GiB"
+            enc = (model.module if hasattr(model, "module") else model).encoder_q
+            g = enc.flat_grads(create=False)
+            if g is not None:
+                if hasattr(model, "wait"):
+                    model.wait()
+                gnorm = float(torch.linalg.vector_norm(g))
+                log += f" | grad: {gnorm:.3g}"
+                if tb_logger:
+                    tb_logger.add_scalar("train/global_grad", gnorm, step)
+            now = time.time()
+            if step > step_last:
+                pairs = (step - step_last) * opt.target_batch_size / (now - t_last)
+                log += f" | pairs/s: {pairs:.0f}"
+            t_last, step_last = now, step
+            if tb_logger:
+                tb_logger.add_scalar("train/lr", lr, step)
+            logger.info(log)
+            run_stats.reset()
+
+        if opt.clip_gradients:
+            if opt.max_grad_value is not None:
+                optimizer.clip_grad_value_(opt.max_grad_value)
+            elif opt.max_grad_norm is not None:
+                optimizer.clip_grad_norm_(opt.max_grad_norm)
+
+        optimizer.step()
+        scheduler.step()
+        model.zero_grad()
+        step += 1
+
+        if dist_utils.is_main() and step % opt.eval_freq == 0 and step > 0:
+            utils.save(model, optimizer, scheduler, step, opt, opt.save_dir, "lastlog")
+        if dist_utils.is_main() and step % opt.save_freq == 0 and step > 0:
+            utils.save(model, optimizer, scheduler, step, opt, opt.save_dir, f"step-{step}")
+    return step
+
+
+def main(argv=None):
+    opt = Options().parse(argv)
+    torch.manual_seed(opt.seed)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("train.py needs an MI355X (there is no CPU path: the product fails loudly instead)")
+    torch.cuda.set_device(local_rank)
+    if world > 1 or "RANK" in os.environ:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    directory_exists = os.path.isdir(os.path.join(opt.output_dir, "checkpoint", "latest")) or os.path.islink(
+        os.path.join(opt.output_dir, "checkpoint", "latest"))
+    dist_utils.barrier()
+    os.makedirs(opt.output_dir, exist_ok=True)
+    if dist_utils.is_main():
+        Options().print_options(opt)
+    dist_utils.barrier()
+    utils.init_logger(opt)
+    os.environ["TOKENIZERS_PARALLELISM"] = "false"
+
+    if opt.contrastive_mode != "moco":
+        raise ValueError(f"contrastive_mode: {opt.contrastive_mode} is outside the MI355X path (moco only)")
+    model_class = moco.MoCo
+
+    if not directory_exists and opt.model_path == "none":
+        model = model_class(opt).cuda()
+        optimizer, scheduler = utils.set_optim(opt, model)
+        step = 0
+    elif directory_exists:
+        model_path = os.path.join(opt.output_dir, "checkpoint", "latest")
+        model, optimizer, scheduler, opt_checkpoint, step = utils.load(model_class, model_path, opt, reset_params=False)
+        logger.info(f"Model loaded from {opt.output_dir}")
+    else:
+        model, optimizer, scheduler, opt_checkpoint, step = utils.load(
+            model_class, opt.model_path, opt, reset_params=False if opt.continue_training else True)
+        if not opt.continue_training:
+            step = 0
+        logger.info(f"Model loaded from {opt.model_path}")
+    logger.info(utils.get_parameters(model))
+
+    if dist.is_initialized():
+        from czech_contriever_amd.parallel import DataParallel
+        model = DataParallel(model, optimizer)
+        dist.barrier()
+
+    logger.info("Start training")
+    step = train(opt, model, optimizer, scheduler, step)
+    if dist_utils.is_main():
+        utils.save(model, optimizer, scheduler, step, opt, opt.save_dir, f"step-{step}")
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
