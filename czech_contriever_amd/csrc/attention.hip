@@ -26,17 +26,33 @@ constexpr float NEG_MASK = -2.0e30f;  // masked score (log2 domain); running max
 
 __device__ __forceinline__ int swz64(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
 
-// stage ROWS x 64 bf16 (rows `row0..`, zero beyond nvalid) into a swizzled LDS tile
+// split staging (issue early / write late): global -> registers now, registers -> swizzled LDS later
 template <int ROWS>
-__device__ __forceinline__ void load_tile(const bf16_t* __restrict__ src, int ld, int nvalid, unsigned char* lds, int tid) {
+struct TileRegs { uint4 v[ROWS * 8 / 256]; };
+template <int ROWS>
+__device__ __forceinline__ void tile_fetch(TileRegs<ROWS>& t, const bf16_t* __restrict__ src, int ld, int nvalid, int tid) {
 #pragma unroll
-  for (int id = tid; id < ROWS * 8; id += 256) {
-    const int row = id >> 3, c = id & 7;
-    uint4 v = {0u, 0u, 0u, 0u};
-    if (row < nvalid) v = *(const uint4*)(src + (size_t)row * ld + c * 8);
-    *(uint4*)(lds + row * 128 + ((c ^ swz64(row)) << 4)) = v;
+  for (int i = 0; i < ROWS * 8 / 256; ++i) {
+    const int id = tid + 256 * i, row = id >> 3, c = id & 7;
+    t.v[i] = (uint4){0u, 0u, 0u, 0u};
+    if (row < nvalid) t.v[i] = *(const uint4*)(src + (size_t)row * ld + c * 8);
   }
 }
+template <int ROWS>
+__device__ __forceinline__ void tile_commit(const TileRegs<ROWS>& t, unsigned char* lds, int tid) {
+#pragma unroll
+  for (int i = 0; i < ROWS * 8 / 256; ++i) {
+    const int id = tid + 256 * i, row = id >> 3, c = id & 7;
+    *(uint4*)(lds + row * 128 + ((c ^ swz64(row)) << 4)) = t.v[i];
+  }
+}
+// sum over the 32 lanes of each half-wave (lanes that share lane>>5), result in every lane
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
 // 32x32x16 A/B operand by rows: lane (r = lane&31, h = lane>>5) holds tile[row0 + r][16ks + 8h .. +7]
 __device__ __forceinline__ bf16x8 frag_row(const unsigned char* lds, int row0, int ks, int lane) {
   const int row = row0 + (lane & 31), c = 2 * ks + (lane >> 5);
@@ -73,6 +89,7 @@ __device__ __forceinline__ float keep16(uint32_t r, int odd, uint32_t thr, float
 struct AttnArgs {
   const bf16_t* qkv; const uint8_t* mask; const bf16_t* ctx; const bf16_t* dctx;
   const float* lse_in; float* lse; float* delta; bf16_t* out; bf16_t* dqkv;
+  float* dbias;  // [3H] bias gradient of the fused QKV projection (column sums of dqkv), may be null
   int B, S, nh, H;
   uint32_t thr, seed, site;
   float inv_keep;
@@ -87,9 +104,9 @@ __device__ __forceinline__ void load_mask_bias(const AttnArgs& a, int b, float* 
 // forward
 // ---------------------------------------------------------------------------------------------
 template <bool DROP>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char kt[64 * 128];
-  __shared__ __attribute__((aligned(16))) unsigned char vt[64 * 128];
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char kt[2][64 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char vt[2][64 * 128];
   __shared__ __attribute__((aligned(16))) float mb[512];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z, hh = blockIdx.y;
@@ -114,70 +131,74 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   float m = -1.0e30f, l = 0.f;
   const uint32_t erow = DROP ? ((uint32_t)((b * a.nh + hh) * S + (q0 + r)) * (uint32_t)S) : 0u;
 
-  for (int kb0 = 0; kb0 < S; kb0 += 64) {
-    __syncthreads();
-    load_tile<64>(base + a.H + (size_t)kb0 * H3, H3, S - kb0, kt, tid);
-    load_tile<64>(base + 2 * a.H + (size_t)kb0 * H3, H3, S - kb0, vt, tid);
-    __syncthreads();
-    if (!active) continue;
-    f32x16 s[2];
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      s[tt] = (f32x16)(0.f);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-        s[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(kt, 32 * tt, ks, lane), bq[ks], s[tt], 0, 0, 0);
+  TileRegs<64> kr, vr;
+  tile_fetch<64>(kr, base + a.H, H3, S, tid);
+  tile_fetch<64>(vr, base + 2 * a.H, H3, S, tid);
+  tile_commit<64>(kr, kt[0], tid);
+  tile_commit<64>(vr, vt[0], tid);
+  int buf = 0;
+  for (int kb0 = 0; kb0 < S; kb0 += 64, buf ^= 1) {
+    __syncthreads();   // tile kb0 is visible; every wave is done with the other buffer
+    const bool more = kb0 + 64 < S;
+    if (more) {
+      tile_fetch<64>(kr, base + a.H + (size_t)(kb0 + 64) * H3, H3, S - kb0 - 64, tid);
+      tile_fetch<64>(vr, base + 2 * a.H + (size_t)(kb0 + 64) * H3, H3, S - kb0 - 64, tid);
     }
-    float mx = m;
+    if (active) {
+#pragma unroll 1
+      for (int tt = 0; tt < 2; ++tt) {
+        f32x16 s = (f32x16)(0.f);
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 bias = *(const f32x4*)(mb + kb0 + 32 * tt + 8 * g + 4 * h);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float x = s[tt][4 * g + j] * c2 + bias[j];
-          s[tt][4 * g + j] = x;
-          mx = fmaxf(mx, x);
-        }
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float alpha = __builtin_amdgcn_exp2f(m - mx);
-    m = mx;
-    float ps = 0.f;
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float p = __builtin_amdgcn_exp2f(s[tt][i] - mx);
-        s[tt][i] = p;
-        ps += p;
-      }
-    l = l * alpha + ps;
-    o[0] *= alpha;
-    o[1] *= alpha;
-    if (DROP) {
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
+        for (int ks = 0; ks < 4; ++ks)
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(kt[buf], 32 * tt, ks, lane), bq[ks], s, 0, 0, 0);
+        float mx = m;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const uint32_t e = erow + (uint32_t)(kb0 + 32 * tt + 8 * g + 4 * h);
-          const uint32_t r0 = czc_rng_pair(a.seed, a.site, e >> 1), r1 = czc_rng_pair(a.seed, a.site, (e >> 1) + 1);
-          s[tt][4 * g + 0] *= keep16(r0, 0, a.thr, a.inv_keep);
-          s[tt][4 * g + 1] *= keep16(r0, 1, a.thr, a.inv_keep);
-          s[tt][4 * g + 2] *= keep16(r1, 0, a.thr, a.inv_keep);
-          s[tt][4 * g + 3] *= keep16(r1, 1, a.thr, a.inv_keep);
+          const f32x4 bias = *(const f32x4*)(mb + kb0 + 32 * tt + 8 * g + 4 * h);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float x = s[4 * g + j] * c2 + bias[j];
+            s[4 * g + j] = x;
+            mx = fmaxf(mx, x);
+          }
         }
-    }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float alpha = __builtin_amdgcn_exp2f(m - mx);
+        m = mx;
+        float ps = 0.f;
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+        for (int i = 0; i < 16; ++i) {
+          const float p = __builtin_amdgcn_exp2f(s[i] - mx);
+          s[i] = p;
+          ps += p;
+        }
+        l = l * alpha + ps;
+        o[0] *= alpha;
+        o[1] *= alpha;
+        if (DROP) {
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 pf = acc_frag(s[tt], s2);
+          for (int g = 0; g < 4; ++g) {
+            const uint32_t e = erow + (uint32_t)(kb0 + 32 * tt + 8 * g + 4 * h);
+            const uint32_t r0 = czc_rng_pair(a.seed, a.site, e >> 1), r1 = czc_rng_pair(a.seed, a.site, (e >> 1) + 1);
+            s[4 * g + 0] *= keep16(r0, 0, a.thr, a.inv_keep);
+            s[4 * g + 1] *= keep16(r0, 1, a.thr, a.inv_keep);
+            s[4 * g + 2] *= keep16(r1, 0, a.thr, a.inv_keep);
+            s[4 * g + 3] *= keep16(r1, 1, a.thr, a.inv_keep);
+          }
+        }
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 32 * tt + 16 * s2, 32 * dt, lane), pf, o[dt], 0, 0, 0);
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pf = acc_frag(s, s2);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt[buf], 32 * tt + 16 * s2, 32 * dt, lane), pf, o[dt], 0, 0, 0);
+        }
       }
+    }
+    if (more) {
+      tile_commit<64>(kr, kt[buf ^ 1], tid);
+      tile_commit<64>(vr, vt[buf ^ 1], tid);
+    }
   }
   if (!active) return;
   l += __shfl_xor(l, 32, 64);
@@ -202,9 +223,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 // backward 1: dQ (and delta = rowsum(dO * O)).  One wave = 32 queries, sweeps 64-key blocks.
 // ---------------------------------------------------------------------------------------------
 template <bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char kt[64 * 128];
-  __shared__ __attribute__((aligned(16))) unsigned char vt[64 * 128];
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char kt[2][64 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char vt[2][64 * 128];
   __shared__ __attribute__((aligned(16))) float mb[512];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z, hh = blockIdx.y;
@@ -242,19 +263,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
   dq[0] = dq[1] = (f32x16)(0.f);
   const uint32_t erow = DROP ? ((uint32_t)((b * a.nh + hh) * S + (q0 + r)) * (uint32_t)S) : 0u;
 
-  for (int kb0 = 0; kb0 < S; kb0 += 64) {
+  TileRegs<64> kr, vr;
+  tile_fetch<64>(kr, base + a.H, H3, S, tid);
+  tile_fetch<64>(vr, base + 2 * a.H, H3, S, tid);
+  tile_commit<64>(kr, kt[0], tid);
+  tile_commit<64>(vr, vt[0], tid);
+  int buf = 0;
+  for (int kb0 = 0; kb0 < S; kb0 += 64, buf ^= 1) {
     __syncthreads();
-    load_tile<64>(base + a.H + (size_t)kb0 * H3, H3, S - kb0, kt, tid);
-    load_tile<64>(base + 2 * a.H + (size_t)kb0 * H3, H3, S - kb0, vt, tid);
-    __syncthreads();
-    if (!active) continue;
-#pragma unroll
+    const bool more = kb0 + 64 < S;
+    if (more) {
+      tile_fetch<64>(kr, base + a.H + (size_t)(kb0 + 64) * H3, H3, S - kb0 - 64, tid);
+      tile_fetch<64>(vr, base + 2 * a.H + (size_t)(kb0 + 64) * H3, H3, S - kb0 - 64, tid);
+    }
+    if (active) {
+#pragma unroll 1
     for (int tt = 0; tt < 2; ++tt) {
       f32x16 s = (f32x16)(0.f), dp = (f32x16)(0.f);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(kt, 32 * tt, ks, lane), bq[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(vt, 32 * tt, ks, lane), bdo[ks], dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(kt[buf], 32 * tt, ks, lane), bq[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(vt[buf], 32 * tt, ks, lane), bdo[ks], dp, 0, 0, 0);
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -277,11 +306,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
         const bf16x8 df = acc_frag(s, s2);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
-          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 32 * tt + 16 * s2, 32 * dt, lane), df, dq[dt], 0, 0, 0);
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt[buf], 32 * tt + 16 * s2, 32 * dt, lane), df, dq[dt], 0, 0, 0);
       }
     }
+    }
+    if (more) {
+      tile_commit<64>(kr, kt[buf ^ 1], tid);
+      tile_commit<64>(vr, vt[buf ^ 1], tid);
+    }
   }
-  if (!active || !qvalid) return;
+  if (!active) return;
+  if (a.dbias) {
+    // bias gradient of the Q projection: column sums over this wave's valid queries
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float v = half_sum(qvalid ? dq[dt][i] * 0.125f : 0.f);
+        if (r == 0) unsafeAtomicAdd(a.dbias + hh * 64 + 32 * dt + (i & 3) + 8 * (i >> 2) + 4 * h, v);
+      }
+  }
+  if (!qvalid) return;
   bf16_t* dst = a.dqkv + ((size_t)b * S + q0 + r) * H3 + hh * 64;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -298,11 +343,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
 // backward 2: dK, dV.  One wave = 32 keys, sweeps 32-query blocks (Q, dO, lse, delta in LDS).
 // ---------------------------------------------------------------------------------------------
 template <bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char qt[32 * 128];
-  __shared__ __attribute__((aligned(16))) unsigned char dot[32 * 128];
-  __shared__ __attribute__((aligned(16))) float lse_s[32];
-  __shared__ __attribute__((aligned(16))) float del_s[32];
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char qt[2][64 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char dot[2][64 * 128];
+  __shared__ __attribute__((aligned(16))) float lse_s[2][64];
+  __shared__ __attribute__((aligned(16))) float del_s[2][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z, hh = blockIdx.y;
   const int S = a.S, H3 = 3 * a.H;
@@ -312,6 +357,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs a) {
   const float c2 = 0.125f * LOG2E;
 
   const bf16_t* base = a.qkv + (size_t)b * S * H3 + hh * 64;
+  const bf16_t* dobase = a.dctx + (size_t)b * S * a.H + hh * 64;
+  const float* lsep = a.lse_in + ((size_t)b * a.nh + hh) * S;
+  const float* delp = a.delta + ((size_t)b * a.nh + hh) * S;
   int kr = k0 + r; if (kr > S - 1) kr = S - 1;
   const bool kvalid = (k0 + r) < S;
   const float kbias = (kvalid && a.mask[(size_t)b * S + kr]) ? 0.f : NEG_MASK;
@@ -325,52 +373,84 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs a) {
   dk[0] = dk[1] = dv[0] = dv[1] = (f32x16)(0.f);
   const uint32_t ebase = (uint32_t)((b * a.nh + hh) * S) * (uint32_t)S + (uint32_t)(k0 + r);
 
-  for (int qb0 = 0; qb0 < S; qb0 += 32) {
-    __syncthreads();
-    load_tile<32>(base + (size_t)qb0 * H3, H3, S - qb0, qt, tid);
-    load_tile<32>(a.dctx + ((size_t)b * S + qb0) * a.H + hh * 64, a.H, S - qb0, dot, tid);
-    if (tid < 32) {
+  TileRegs<64> qr, dr;
+  float lreg = 0.f, dreg = 0.f;
+  auto fetch = [&](int qb0) {
+    tile_fetch<64>(qr, base + (size_t)qb0 * H3, H3, S - qb0, tid);
+    tile_fetch<64>(dr, dobase + (size_t)qb0 * a.H, a.H, S - qb0, tid);
+    if (tid < 64) {
       const int q = qb0 + tid;
-      lse_s[tid] = (q < S) ? a.lse_in[((size_t)b * a.nh + hh) * S + q] * LOG2E : 1.0e30f;
-      del_s[tid] = (q < S) ? a.delta[((size_t)b * a.nh + hh) * S + q] : 0.f;
+      lreg = (q < S) ? lsep[q] * LOG2E : 1.0e30f;
+      dreg = (q < S) ? delp[q] : 0.f;
     }
+  };
+  auto commit = [&](int bufi) {
+    tile_commit<64>(qr, qt[bufi], tid);
+    tile_commit<64>(dr, dot[bufi], tid);
+    if (tid < 64) { lse_s[bufi][tid] = lreg; del_s[bufi][tid] = dreg; }
+  };
+  fetch(0);
+  commit(0);
+  int buf = 0;
+  for (int qb0 = 0; qb0 < S; qb0 += 64, buf ^= 1) {
     __syncthreads();
-    if (!active) continue;
-    f32x16 s = (f32x16)(0.f), dp = (f32x16)(0.f);
+    const bool more = qb0 + 64 < S;
+    if (more) fetch(qb0 + 64);
+    if (active) {
+#pragma unroll 1
+      for (int hf = 0; hf < 2; ++hf) {
+        if (qb0 + 32 * hf < S) {   // wave-uniform
+          f32x16 s = (f32x16)(0.f), dp = (f32x16)(0.f);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(qt, 0, ks, lane), bk[ks], s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(dot, 0, ks, lane), bv[ks], dp, 0, 0, 0);
-    }
-    // rows (registers) are queries 8g + 4h + j, the lane is the key
+          for (int ks = 0; ks < 4; ++ks) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(qt[buf], 32 * hf, ks, lane), bk[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(dot[buf], 32 * hf, ks, lane), bv[ks], dp, 0, 0, 0);
+          }
+          // rows (registers) are queries 32hf + 8g + 4h + j, the lane is the key
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 l4 = *(const f32x4*)(lse_s + 8 * g + 4 * h);
-      const f32x4 d4 = *(const f32x4*)(del_s + 8 * g + 4 * h);
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 l4 = *(const f32x4*)(&lse_s[buf][32 * hf + 8 * g + 4 * h]);
+            const f32x4 d4 = *(const f32x4*)(&del_s[buf][32 * hf + 8 * g + 4 * h]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float p = __builtin_amdgcn_exp2f(s[4 * g + j] * c2 + kbias - l4[j]);
-        float z = 1.f;
-        if (DROP) {
-          const uint32_t e = ebase + (uint32_t)(qb0 + 8 * g + 4 * h + j) * (uint32_t)S;
-          z = keep16(czc_rng_pair(a.seed, a.site, e >> 1), (int)(e & 1u), a.thr, a.inv_keep);
+            for (int j = 0; j < 4; ++j) {
+              const float p = __builtin_amdgcn_exp2f(s[4 * g + j] * c2 + kbias - l4[j]);
+              float z = 1.f;
+              if (DROP) {
+                const uint32_t e = ebase + (uint32_t)(qb0 + 32 * hf + 8 * g + 4 * h + j) * (uint32_t)S;
+                z = keep16(czc_rng_pair(a.seed, a.site, e >> 1), (int)(e & 1u), a.thr, a.inv_keep);
+              }
+              const float dpz = z * dp[4 * g + j];
+              dp[4 * g + j] = p * (dpz - d4[j]);  // dS
+              s[4 * g + j] = p * z;               // P~
+            }
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pf = acc_frag(s, s2), df = acc_frag(dp, s2);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+              dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot[buf], 32 * hf + 16 * s2, 32 * dt, lane), pf, dv[dt], 0, 0, 0);
+              dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt[buf], 32 * hf + 16 * s2, 32 * dt, lane), df, dk[dt], 0, 0, 0);
+            }
+          }
         }
-        const float dpz = z * dp[4 * g + j];
-        dp[4 * g + j] = p * (dpz - d4[j]);  // dS
-        s[4 * g + j] = p * z;               // P~
       }
     }
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const bf16x8 pf = acc_frag(s, s2), df = acc_frag(dp, s2);
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot, 16 * s2, 32 * dt, lane), pf, dv[dt], 0, 0, 0);
-        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 16 * s2, 32 * dt, lane), df, dk[dt], 0, 0, 0);
-      }
-    }
+    if (more) commit(buf ^ 1);
   }
-  if (!active || !kvalid) return;
+  if (!active) return;
+  if (a.dbias) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int d = hh * 64 + 32 * dt + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const float vk = half_sum(kvalid ? dk[dt][i] * 0.125f : 0.f);
+        const float vv = half_sum(kvalid ? dv[dt][i] : 0.f);
+        if (r == 0) { unsafeAtomicAdd(a.dbias + a.H + d, vk); unsafeAtomicAdd(a.dbias + 2 * a.H + d, vv); }
+      }
+  }
+  if (!kvalid) return;
   bf16_t* dstk = a.dqkv + ((size_t)b * S + k0 + r) * H3 + a.H + hh * 64;
   bf16_t* dstv = dstk + a.H;
 #pragma unroll
@@ -418,10 +498,10 @@ extern "C" int czc_attention_forward(const uint16_t* qkv, const uint8_t* mask, i
 extern "C" int czc_attention_backward(const uint16_t* qkv, const uint8_t* mask, const uint16_t* ctx,
                                       const uint16_t* dctx, const float* lse, int batch, int seq, int heads,
                                       float dropout_p, uint32_t seed, uint32_t site, float* delta, uint16_t* dqkv,
-                                      czc_stream_t stream) {
+                                      float* d_bias_qkv, czc_stream_t stream) {
   if (int rc = attn_check("czc_attention_backward", batch, seq, heads, dropout_p)) return rc;
   AttnArgs a{};
-  a.qkv = qkv; a.mask = mask; a.ctx = ctx; a.dctx = dctx; a.lse_in = lse; a.delta = delta; a.dqkv = dqkv;
+  a.qkv = qkv; a.mask = mask; a.ctx = ctx; a.dctx = dctx; a.lse_in = lse; a.delta = delta; a.dqkv = dqkv; a.dbias = d_bias_qkv;
   a.B = batch; a.S = seq; a.nh = heads; a.H = heads * 64;
   a.thr = dropout_p > 0.f ? czc_drop_thr(dropout_p) : 0u;
   a.inv_keep = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f;

@@ -84,12 +84,31 @@ __host__ __device__ __forceinline__ uint32_t czc_drop_thr(float p) {
   return (uint32_t)(p * 65536.0f + 0.5f);
 }
 
-// exact erf-GELU and its derivative (HF "gelu")
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf-GELU (HF "gelu") and its derivative with ONE v_exp_f32 and ONE v_rcp_f32 per element:
+//   Phi(x) = 0.5 (1 + erf(x / sqrt 2)),  erf(z) = 1 - (a1 t + ... + a5 t^5) exp(-z^2),  t = 1 / (1 + p z),  z >= 0
+//   (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7: far below the bf16 rounding of the stored result; libm's
+//   erff costs ~3x the instructions and made the FFN epilogues VALU-bound).  exp(-z^2) = exp(-x^2 / 2) is also
+//   the Gaussian factor of gelu'(x) = Phi(x) + x phi(x), so the derivative costs no second exponential.
+struct GeluParts { float cdf, pdf; };
+__device__ __forceinline__ GeluParts gelu_parts(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);  // exp(-x^2/2)
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  float poly = 1.061405429f;
+  poly = poly * t - 1.453152027f;
+  poly = poly * t + 1.421413741f;
+  poly = poly * t - 0.284496736f;
+  poly = poly * t + 0.254829592f;
+  const float erfc_half = 0.5f * poly * t * e;          // 0.5 * erfc(z)
+  GeluParts g;
+  g.cdf = x >= 0.f ? 1.0f - erfc_half : erfc_half;
+  g.pdf = 0.39894228040143267794f * e;
+  return g;
+}
+__device__ __forceinline__ float gelu_f(float x) { return x * gelu_parts(x).cdf; }
 __device__ __forceinline__ float dgelu_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  const GeluParts g = gelu_parts(x);
+  return g.cdf + x * g.pdf;
 }
 
 // 16 bytes of zeros in global memory: out-of-range 16-B chunks of GEMM / attention operands are

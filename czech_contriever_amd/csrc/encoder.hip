@@ -135,8 +135,9 @@ static BwdLayout bwd_layout(const czc_bert_shape* s, int B, int S) {
 #define SITE_H2(l) (16u * ((l) + 1) + 2u)
 
 static int gemm(int al, int bl, int epi, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
-                int ldc, const float* bias, const void* aux, void* C2, int splitk, hipStream_t st) {
+                int ldc, const float* bias, const void* aux, void* C2, int splitk, hipStream_t st, float* colsum = nullptr) {
   GemmArgs a{};
+  a.colsum = colsum;
   a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C; a.C2 = C2; a.bias = bias; a.aux = (const bf16_t*)aux;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   return gemm_dispatch(al, bl, epi, a, splitk, st);
@@ -255,8 +256,7 @@ extern "C" int czc_encoder_backward(const czc_bert_shape* s, const float* params
     RC(czc_residual_ln_backward(g0, nullptr, BUF(w.y2), BUF(w.x1), FBUF(w.st2), M, H, PF(CZC_P_LN2W, l), ph, seed,
                                 SITE_H2(l), Z, Y, GF(CZC_P_LN2W, l), GF(CZC_P_LN2B, l), GF(CZC_P_B2, l), stream));
     RC(dweight(H, I, Y, H, BUF(w.hact), I, GF(CZC_P_W2, l)));
-    RC(gemm(0, 1, EPI_DGELU, M, I, H, Y, H, WB(CZC_P_W2, l), I, U, I, nullptr, BUF(w.u), nullptr, 1, st));
-    RC(czc_colsum_bf16(U, M, I, I, GF(CZC_P_B1, l), stream));
+    RC(gemm(0, 1, EPI_DGELU, M, I, H, Y, H, WB(CZC_P_W2, l), I, U, I, nullptr, BUF(w.u), nullptr, 1, st, GF(CZC_P_B1, l)));
     RC(dweight(I, H, U, I, BUF(w.x1), H, GF(CZC_P_W1, l)));
     RC(gemm(0, 1, EPI_ADD, M, H, I, U, I, WB(CZC_P_W1, l), H, X1, H, nullptr, Z, nullptr, 1, st));
     // x1 = LN(drop(y1) + x[l])
@@ -264,8 +264,8 @@ extern "C" int czc_encoder_backward(const czc_bert_shape* s, const float* params
                                 SITE_H1(l), Z, Y, GF(CZC_P_LN1W, l), GF(CZC_P_LN1B, l), GF(CZC_P_BO, l), stream));
     RC(dweight(H, H, Y, H, BUF(w.ctx), H, GF(CZC_P_WO, l)));
     RC(gemm(0, 1, EPI_STORE, M, H, H, Y, H, WB(CZC_P_WO, l), H, C, H, nullptr, nullptr, nullptr, 1, st));
-    RC(czc_attention_backward(BUF(w.qkv), mask, BUF(w.ctx), C, FBUF(w.lse), batch, seq, nh, pa, seed, SITE_ATTN(l), delta, Q3, stream));
-    RC(czc_colsum_bf16(Q3, M, 3 * H, 3 * H, GF(CZC_P_BQKV, l), stream));
+    RC(czc_attention_backward(BUF(w.qkv), mask, BUF(w.ctx), C, FBUF(w.lse), batch, seq, nh, pa, seed, SITE_ATTN(l), delta, Q3,
+                              GF(CZC_P_BQKV, l), stream));
     RC(dweight(3 * H, H, Q3, 3 * H, BUF(e.x[l]), H, GF(CZC_P_WQKV, l)));
     RC(gemm(0, 1, EPI_ADD, M, H, 3 * H, Q3, 3 * H, WB(CZC_P_WQKV, l), H, g0, H, nullptr, Z, nullptr, 1, st));
   }

@@ -10,10 +10,12 @@ struct GemmArgs {
   const float* bias; const bf16_t* aux;
   const float* rowv;     // per-row vector (head: lse)
   float* part;           // head partials [3][tilesN][M]
+  float* colsum;         // optional [N]: += column sums of C (DGELU epilogue: bias gradient)
   int M, N, K;
   int lda, ldb, ldc;
   int tiles_m, tiles_n;
   int ktiles_per_split;  // K tiles handled by one split
+  int cfg;               // tile configuration: 0 = default, 1 = 256x256 (8 waves), 2 = 128x128 (4 waves, 2 WG/CU)
   float alpha;           // head: 1/T
   float beta;            // head: eps/(K+1)
 };

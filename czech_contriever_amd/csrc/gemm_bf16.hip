@@ -25,10 +25,20 @@
 
 namespace czc {
 
-constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int TILE_BYTES = 256 * 64 * 2;          // 32 KiB per operand tile
-constexpr int BUF_BYTES = 2 * TILE_BYTES;         // A + B
-constexpr int GEMM_LDS = 2 * BUF_BYTES;           // 128 KiB
+constexpr int BK = 64;
+// Tile configuration: WM x WN waves, each owning (TM*16) x 64 outputs.
+//   big   = 2x4 waves, TM 8: 256x256 tile, 512 threads, 128 KiB LDS, one workgroup per CU
+//   small = 2x2 waves, TM 4: 128x128 tile, 256 threads,  64 KiB LDS, two workgroups per CU (a workgroup's
+//           epilogue stores and tile prologue overlap the other's MFMA work)
+template <int WM_, int WN_, int TM_>
+struct Cfg {
+  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = 4;
+  static constexpr int NW = WM * WN, NT = NW * 64;
+  static constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  static constexpr int TILE_A = BM * BK * 2, TILE_B = BN * BK * 2;
+  static constexpr int BUF = TILE_A + TILE_B;
+  static constexpr int LDS = 2 * BUF;
+};
 
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
@@ -39,11 +49,13 @@ __device__ __forceinline__ void glds16(const void* src, lptr_t dst) {
 
 // ---- staging -------------------------------------------------------------------------------
 // K-major operand: X[rows][ld], tile = rows [row0, row0+256) x k [k0, k0+64)
+template <int ROWS, int NW>
 __device__ __forceinline__ void stage_kmajor(const bf16_t* X, int ld, int row0, int nrows, int k0, int kdim,
                                              unsigned char* tile, int wave, int lane) {
+  constexpr int PER = ROWS / 8 / NW;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q = wave * 4 + i;            // 1-KiB piece: rows 8q .. 8q+7
+  for (int i = 0; i < PER; ++i) {
+    const int q = wave * PER + i;          // 1-KiB piece: rows 8q .. 8q+7
     const int r = 8 * q + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
     const int gr = row0 + r, gk = k0 + c * 8;
@@ -52,11 +64,13 @@ __device__ __forceinline__ void stage_kmajor(const bf16_t* X, int ld, int row0, 
   }
 }
 // MN-major operand: X[kdim][ld] (free index contiguous), tile = k [k0,k0+64) x cols [col0, col0+256)
+template <int COLS, int NW>
 __device__ __forceinline__ void stage_mnmajor(const bf16_t* X, int ld, int col0, int ncols, int k0, int kdim,
                                               unsigned char* tile, int wave, int lane) {
+  constexpr int PER = COLS / 128 * 16 / NW;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q = wave * 4 + i;            // piece q: block q>>4, k-rows 4*(q&15) .. +3
+  for (int i = 0; i < PER; ++i) {
+    const int q = wave * PER + i;          // piece q: block q>>4, k-rows 4*(q&15) .. +3
     const int blk = q >> 4;
     const int kr = 4 * (q & 15) + (lane >> 4);
     const int ch = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
@@ -99,13 +113,15 @@ __device__ __forceinline__ void swizzle_tile(int bid, int nwg, int tiles_n, int&
   tn = swz - tm * tiles_n;
 }
 
-template <int AL, int BL, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs a) {
+template <int AL, int BL, int EPI, class CF>
+__global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BM = CF::BM, BN = CF::BN, TM = CF::TM, WN = CF::WN;
+  constexpr int TILE_BYTES_A = CF::TILE_A, BUF_BYTES = CF::BUF;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / WN, wn = wave % WN;
 
   int tm, tn;
   swizzle_tile(blockIdx.x, gridDim.x, a.tiles_n, tm, tn);
@@ -117,44 +133,90 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs a) {
   if (kt_end > kt_total) kt_end = kt_total;
   const int nt = kt_end - kt_begin;
 
-  f32x4 acc[8][4];
+  f32x4 acc[TM][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   auto stage = [&](int t, int buf) {
     unsigned char* ta = smem + buf * BUF_BYTES;
-    unsigned char* tb = ta + TILE_BYTES;
+    unsigned char* tb = ta + TILE_BYTES_A;
     const int k0 = (kt_begin + t) * BK;
-    if (AL == 0) stage_kmajor(a.A, a.lda, row0, a.M, k0, a.K, ta, wave, lane);
-    else         stage_mnmajor(a.A, a.lda, row0, a.M, k0, a.K, ta, wave, lane);
-    if (BL == 0) stage_kmajor(a.B, a.ldb, col0, a.N, k0, a.K, tb, wave, lane);
-    else         stage_mnmajor(a.B, a.ldb, col0, a.N, k0, a.K, tb, wave, lane);
+    if (AL == 0) stage_kmajor<BM, CF::NW>(a.A, a.lda, row0, a.M, k0, a.K, ta, wave, lane);
+    else         stage_mnmajor<BM, CF::NW>(a.A, a.lda, row0, a.M, k0, a.K, ta, wave, lane);
+    if (BL == 0) stage_kmajor<BN, CF::NW>(a.B, a.ldb, col0, a.N, k0, a.K, tb, wave, lane);
+    else         stage_mnmajor<BN, CF::NW>(a.B, a.ldb, col0, a.N, k0, a.K, tb, wave, lane);
   };
 
-  if (nt > 0) stage(0, 0);
-  for (int t = 0; t < nt; ++t) {
+  // Software pipeline, 4 phases per K-tile (2 k-steps x 2 halves of the wave's rows), one barrier per K-tile.
+  // While the MFMAs of one phase run, the LDS reads of the next phase's fragments are in flight:
+  //   phase 0: MFMA(t, ks0, rows lo)   || read A(t, ks0, hi)
+  //   phase 1: MFMA(t, ks0, rows hi)   || read A(t, ks1, lo), B(t, ks1)
+  //   phase 2: MFMA(t, ks1, rows lo)   || read A(t, ks1, hi)
+  //   ---- vmcnt(0): tile t+1 landed; barrier: every wave has finished reading tile t ----
+  //   global_load_lds of tile t+2 into tile t's buffer (lands during the next K-tile)
+  //   phase 3: MFMA(t, ks1, rows hi)   || read A(t+1, ks0, lo), B(t+1, ks0)
+  constexpr int HM = TM / 2;
+  bf16x8 fa0[HM], fa1[HM], fb0[4], fb1[4];
+  auto read_a = [&](bf16x8 (&fa)[HM], int buf, int ks, int half) {
+    const unsigned char* ta = smem + buf * BUF_BYTES;
+#pragma unroll
+    for (int i = 0; i < HM; ++i)
+      fa[i] = (AL == 0) ? frag_kmajor(ta, wm * TM * 16, half * HM + i, ks, lane)
+                        : frag_mnmajor(ta, wm * TM * 16, half * HM + i, ks, lane);
+  };
+  auto read_b = [&](bf16x8 (&fb)[4], int buf, int ks) {
+    const unsigned char* tb = smem + buf * BUF_BYTES + TILE_BYTES_A;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      fb[j] = (BL == 0) ? frag_kmajor(tb, wn * 64, j, ks, lane) : frag_mnmajor(tb, wn * 64, j, ks, lane);
+  };
+#define CZC_MFMA_HALF(FA, FB, HALF)                                                                  \
+  _Pragma("unroll") for (int i = 0; i < HM; ++i)                                                     \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
+    acc[(HALF) * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j], FA[i], acc[(HALF) * HM + i][j], 0, 0, 0)
+
+  if (nt > 0) {
+    stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                       // tile t landed for every wave; buffer (t+1)&1 is free
-    if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
-    const unsigned char* ta = smem + (t & 1) * BUF_BYTES;
-    const unsigned char* tb = ta + TILE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 bf[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        bf[j] = (BL == 0) ? frag_kmajor(tb, wn * 64, j, ks, lane) : frag_mnmajor(tb, wn * 64, j, ks, lane);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const bf16x8 af = (AL == 0) ? frag_kmajor(ta, wm * 128, i, ks, lane) : frag_mnmajor(ta, wm * 128, i, ks, lane);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af, acc[i][j], 0, 0, 0);
-      }
-    }
+    __syncthreads();
+    if (nt > 1) stage(1, 1);
+    read_a(fa0, 0, 0, 0);
+    read_b(fb0, 0, 0);
   }
+  // pin the issue order inside each phase: one LDS read, then a few MFMAs, ... (the scheduler otherwise sinks the
+  // reads to just before their first use and the MFMA pipe waits out every LDS round trip)
+  constexpr int RA = (AL == 0) ? 1 : 2, RB = (BL == 0) ? 1 : 2;   // ds instructions per fragment
+#define CZC_INTERLEAVE(NREADS, NMFMA)                                                      \
+  _Pragma("unroll") for (int q_ = 0; q_ < (NREADS); ++q_) {                                 \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                      \
+    __builtin_amdgcn_sched_group_barrier(0x008, (NMFMA) / (NREADS), 0);                     \
+  }
+  constexpr int NM = HM * 4;  // MFMAs per phase
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    read_a(fa1, buf, 0, 1);
+    CZC_MFMA_HALF(fa0, fb0, 0);
+    CZC_INTERLEAVE(HM * RA, NM)
+    read_a(fa0, buf, 1, 0);
+    read_b(fb1, buf, 1);
+    CZC_MFMA_HALF(fa1, fb0, 1);
+    CZC_INTERLEAVE(HM * RA + 4 * RB, NM)
+    read_a(fa1, buf, 1, 1);
+    CZC_MFMA_HALF(fa0, fb1, 0);
+    CZC_INTERLEAVE(HM * RA, NM)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 2 < nt) stage(t + 2, buf);
+    // (after the last tile these read the other buffer's stale bytes: never used, and it keeps the block branch-free)
+    read_a(fa0, buf ^ 1, 0, 0);
+    read_b(fb0, buf ^ 1, 0);
+    CZC_MFMA_HALF(fa1, fb1, 1);
+    CZC_INTERLEAVE(HM * RA + 4 * RB, NM)
+  }
+#undef CZC_INTERLEAVE
+#undef CZC_MFMA_HALF
 
   // ---------------- epilogue ----------------
   // acc[i][j][r] = C[row0 + wm*128 + 16i + (lane&15)][col0 + wn*64 + 16j + 4(lane>>4) + r]
@@ -163,8 +225,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs a) {
   if (EPI == EPI_F32) {
     float* C = (float*)a.C + (size_t)split * a.M * a.ldc;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = row0 + wm * 128 + 16 * i + mrow;
+    for (int i = 0; i < TM; ++i) {
+      const int m = row0 + wm * TM * 16 + 16 * i + mrow;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int n = col0 + wn * 64 + 16 * j + 4 * nq;
@@ -177,9 +239,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs a) {
   if (EPI == EPI_LSE) {
     // per-row partial (max, sum exp, sum) over this tile's valid columns of z = alpha*acc
     __syncthreads();
-    float* red = (float*)smem;  // [3][4 wn][256 rows]
+    float* red = (float*)smem;  // [3][WN][BM rows]
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < TM; ++i) {
       float mx = -1e30f, sm = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -202,23 +264,23 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs a) {
       se += __shfl_xor(se, 16, 64); se += __shfl_xor(se, 32, 64);
       sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
       if (nq == 0) {
-        const int ml = wm * 128 + 16 * i + mrow;
-        red[(0 * 4 + wn) * 256 + ml] = mx;
-        red[(1 * 4 + wn) * 256 + ml] = se;
-        red[(2 * 4 + wn) * 256 + ml] = sm;
+        const int ml = wm * TM * 16 + 16 * i + mrow;
+        red[(0 * WN + wn) * BM + ml] = mx;
+        red[(1 * WN + wn) * BM + ml] = se;
+        red[(2 * WN + wn) * BM + ml] = sm;
       }
     }
     __syncthreads();
-    if (tid < 256) {
+    if (tid < BM) {
       const int m = row0 + tid;
       float mx = -1e30f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) mx = fmaxf(mx, red[(0 * 4 + w) * 256 + tid]);
+      for (int w = 0; w < WN; ++w) mx = fmaxf(mx, red[(0 * WN + w) * BM + tid]);
       float se = 0.f, sm = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        se += red[(1 * 4 + w) * 256 + tid] * __expf(red[(0 * 4 + w) * 256 + tid] - mx);
-        sm += red[(2 * 4 + w) * 256 + tid];
+      for (int w = 0; w < WN; ++w) {
+        se += red[(1 * WN + w) * BM + tid] * __expf(red[(0 * WN + w) * BM + tid] - mx);
+        sm += red[(2 * WN + w) * BM + tid];
       }
       if (m < a.M) {
         const size_t pl = (size_t)a.tiles_n * a.M;
@@ -233,13 +295,13 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs a) {
   // bf16 outputs: registers -> LDS (per-wave 128 x 64 bf16 region, 16-B chunks XOR-swizzled by
   // row&7) -> 16-B row segments -> global
   __syncthreads();  // all waves are done reading the operand tiles
-  unsigned char* reg = smem + wave * 16384;
+  unsigned char* reg = smem + wave * (TM * 16 * 128);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < TM; ++i) {
     const int rl = 16 * i + mrow;
     float rv = 0.f;
     if (EPI == EPI_SOFTGRAD) {
-      const int m = row0 + wm * 128 + rl;
+      const int m = row0 + wm * TM * 16 + rl;
       rv = (m < a.M) ? a.rowv[m] : 0.f;
     }
 #pragma unroll
@@ -265,11 +327,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs a) {
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes are done (region is wave-private)
   bf16_t* C = (bf16_t*)a.C;
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // DGELU: this lane's 8 columns over its 2*TM rows
 #pragma unroll 4
-  for (int it = 0; it < 16; ++it) {
+  for (int it = 0; it < 2 * TM; ++it) {
     const int idx = it * 64 + lane;
     const int rl = idx >> 3, ch = idx & 7;
-    const int m = row0 + wm * 128 + rl;
+    const int m = row0 + wm * TM * 16 + rl;
     const int n = col0 + wn * 64 + ch * 8;
     if (m < a.M && n < a.N) {
       uint4 v = *(const uint4*)(reg + rl * 128 + ((ch ^ (rl & 7)) << 4));
@@ -284,12 +347,16 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs a) {
         *(uint4*)((bf16_t*)a.C2 + off) = g;
       } else if (EPI == EPI_DGELU) {
         const uint4 u = *(const uint4*)(a.aux + off);
+        float e[8];
+        e[0] = bflo(v.x) * dgelu_f(bflo(u.x)); e[1] = bfhi(v.x) * dgelu_f(bfhi(u.x));
+        e[2] = bflo(v.y) * dgelu_f(bflo(u.y)); e[3] = bfhi(v.y) * dgelu_f(bfhi(u.y));
+        e[4] = bflo(v.z) * dgelu_f(bflo(u.z)); e[5] = bfhi(v.z) * dgelu_f(bfhi(u.z));
+        e[6] = bflo(v.w) * dgelu_f(bflo(u.w)); e[7] = bfhi(v.w) * dgelu_f(bfhi(u.w));
         uint4 g;
-        g.x = pack2bf(bflo(v.x) * dgelu_f(bflo(u.x)), bfhi(v.x) * dgelu_f(bfhi(u.x)));
-        g.y = pack2bf(bflo(v.y) * dgelu_f(bflo(u.y)), bfhi(v.y) * dgelu_f(bfhi(u.y)));
-        g.z = pack2bf(bflo(v.z) * dgelu_f(bflo(u.z)), bfhi(v.z) * dgelu_f(bfhi(u.z)));
-        g.w = pack2bf(bflo(v.w) * dgelu_f(bflo(u.w)), bfhi(v.w) * dgelu_f(bfhi(u.w)));
+        g.x = pack2bf(e[0], e[1]); g.y = pack2bf(e[2], e[3]); g.z = pack2bf(e[4], e[5]); g.w = pack2bf(e[6], e[7]);
         *(uint4*)(C + off) = g;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) csum[j] += e[j];
       } else if (EPI == EPI_ADD) {
         const uint4 u = *(const uint4*)(a.aux + off);
         uint4 g;
@@ -303,21 +370,50 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs a) {
       }
     }
   }
+  if (EPI == EPI_DGELU && a.colsum) {
+    // lanes with equal (lane & 7) own the same 8 columns: fold the 8 row groups, then 8 lanes x 8 atomics
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = csum[j];
+      t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+      csum[j] = t;
+    }
+    const int n = col0 + wn * 64 + (lane & 7) * 8;
+    if ((lane >> 3) == 0 && n < a.N) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) unsafeAtomicAdd(a.colsum + n + j, csum[j]);
+    }
+  }
 }
 
 // ---- host launcher ---------------------------------------------------------------------------
-template <int AL, int BL, int EPI>
-static int launch(const GemmArgs& a, int splits, hipStream_t st) {
+typedef Cfg<2, 4, 8> CfgBig;
+typedef Cfg<2, 2, 4> CfgSmall;
+static int g_tile_override = 0;  // 0 = heuristic, 1 = 256x256, 2 = 128x128
+
+template <int AL, int BL, int EPI, class CF>
+static int launch_cfg(GemmArgs a, int splits, hipStream_t st) {
   static bool attr_done = false;
-  auto kern = gemm_kernel<AL, BL, EPI>;
+  auto kern = gemm_kernel<AL, BL, EPI, CF>;
   if (!attr_done) {
-    CZC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
+    CZC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS));
     attr_done = true;
   }
+  a.tiles_m = ceil_div(a.M, CF::BM);
+  a.tiles_n = ceil_div(a.N, CF::BN);
   dim3 grid(a.tiles_m * a.tiles_n, splits, 1);
-  hipLaunchKernelGGL(kern, grid, dim3(512), GEMM_LDS, st, a);
+  hipLaunchKernelGGL(kern, grid, dim3(CF::NT), CF::LDS, st, a);
   CZC_LAUNCH_CHECK();
   return CZC_OK;
+}
+
+template <int AL, int BL, int EPI>
+static int launch(const GemmArgs& a, int splits, hipStream_t st) {
+  int cfg = a.cfg ? a.cfg : g_tile_override;
+  if (EPI == EPI_LSE || EPI == EPI_SOFTGRAD) cfg = 1;
+  if (cfg == 0) cfg = 1;
+  if (cfg == 2) return launch_cfg<AL, BL, EPI, CfgSmall>(a, splits, st);
+  return launch_cfg<AL, BL, EPI, CfgBig>(a, splits, st);
 }
 
 template <int EPI>
@@ -365,8 +461,6 @@ static int gemm_dispatch_inner(int al, int bl, int epi, GemmArgs a, int splitk, 
   if (bl == 0) CZC_REQUIRE((a.K % 8) == 0, "czc_gemm: K=%d must be a multiple of 8 for a K-major B", a.K);
   CZC_REQUIRE(splitk >= 1, "czc_gemm: splitk=%d", splitk);
   CZC_REQUIRE(splitk == 1 || epi == EPI_F32, "czc_gemm: split-K needs the f32 slab epilogue");
-  a.tiles_m = ceil_div(a.M, BM);
-  a.tiles_n = ceil_div(a.N, BN);
   const int kt = ceil_div(a.K, BK);
   a.ktiles_per_split = ceil_div(kt, splitk);
   switch (epi) {
@@ -413,6 +507,12 @@ extern "C" int czc_gemm_bf16(int a_layout, int b_layout, int epilogue, int M, in
   a.A = A; a.B = B; a.C = C; a.C2 = C2; a.bias = bias; a.aux = aux;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   return gemm_dispatch(a_layout, b_layout, epilogue, a, splitk, (hipStream_t)stream);
+}
+
+extern "C" int czc_gemm_set_tile(int cfg) {
+  CZC_REQUIRE(cfg >= 0 && cfg <= 2, "czc_gemm_set_tile: cfg=%d (0 heuristic, 1 = 256x256, 2 = 128x128)", cfg);
+  g_tile_override = cfg;
+  return CZC_OK;
 }
 
 extern "C" int czc_probe_arm(int a_layout, int b_layout, int epilogue, int M, int N, int K, int max_samples) {

@@ -19,19 +19,21 @@ __device__ __forceinline__ void st_bf4g(bf16_t* p, f32x4 v) {
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ pk, const float* __restrict__ pq, int64_t n4,
                                                   int64_t n, float m, float om, bf16_t* __restrict__ pk_bf,
                                                   int64_t n_bf) {
+#pragma clang fp contract(off)  // the two products must round separately (no FMA), as torch computes them
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     const f32x4 a = ((const f32x4*)pk)[i], b = ((const f32x4*)pq)[i];
     f32x4 r;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = __fadd_rn(__fmul_rn(a[j], m), __fmul_rn(b[j], om));
+    for (int j = 0; j < 4; ++j) { const float p1 = a[j] * m, p2 = b[j] * om; r[j] = p1 + p2; }
     ((f32x4*)pk)[i] = r;
     if (i * 4 + 3 < n_bf) st_bf4g(pk_bf + i * 4, r);
   }
   // tail (n not a multiple of 4)
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const int64_t i = (n4 << 2) + threadIdx.x;
-    const float r = __fadd_rn(__fmul_rn(pk[i], m), __fmul_rn(pq[i], om));
+    const float p1 = pk[i] * m, p2 = pq[i] * om;
+    const float r = p1 + p2;
     pk[i] = r;
     if (i < n_bf) pk_bf[i] = f2bf(r);
   }

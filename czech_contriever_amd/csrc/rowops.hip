@@ -9,7 +9,7 @@
 
 namespace czc {
 
-constexpr int NIT = 4;  // hidden <= 64 lanes * 4 chunks * 4 elements = 1024
+// NIT = float4 chunks per lane: hidden <= 64 lanes * NIT * 4 elements (NIT = 3 for 768, 4 up to 1024)
 
 __device__ __forceinline__ f32x4 ld_bf4(const bf16_t* p) {
   const uint2 w = *(const uint2*)p;
@@ -36,6 +36,7 @@ __device__ __forceinline__ f32x4 drop_scale4(uint32_t seed, uint32_t site, uint3
 struct LnStat { float mean, rstd; };
 
 // mean / rstd of a row held as v[NIT] chunks (invalid chunks must be zero)
+template <int NIT>
 __device__ __forceinline__ LnStat row_stats(const f32x4* v, int H, int lane, float eps) {
   float s = 0.f;
 #pragma unroll
@@ -56,6 +57,7 @@ __device__ __forceinline__ LnStat row_stats(const f32x4* v, int H, int lane, flo
 // ---------------------------------------------------------------------------------------------
 // x = LN(dropout(y) + resid)
 // ---------------------------------------------------------------------------------------------
+template <int NIT>
 __global__ __launch_bounds__(256) void residual_ln_fwd_kernel(
     const bf16_t* __restrict__ y, const bf16_t* __restrict__ resid, int rows, int H,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256) void residual_ln_fwd_kernel(
         z[it] = a + ld_bf4(resid + base + c);
       }
     }
-    const LnStat st = row_stats(z, H, lane, eps);
+    const LnStat st = row_stats<NIT>(z, H, lane, eps);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int c = (lane + 64 * it) * 4;
@@ -90,6 +92,7 @@ __global__ __launch_bounds__(256) void residual_ln_fwd_kernel(
 // ---------------------------------------------------------------------------------------------
 // backward of the above.  dz_out: gradient w.r.t. (dropout(y) + resid); dy_out: w.r.t. y.
 // ---------------------------------------------------------------------------------------------
+template <int NIT>
 __device__ __forceinline__ void flush_colsums(float* lds_acc, const f32x4 (&acc)[3][NIT], int H, int lane,
                                               float* d0, float* d1, float* d2) {
   // lds_acc [3][1024] zeroed by the caller; waves add their lane-private partial sums
@@ -111,6 +114,7 @@ __device__ __forceinline__ void flush_colsums(float* lds_acc, const f32x4 (&acc)
   }
 }
 
+template <int NIT>
 __global__ __launch_bounds__(256) void residual_ln_bwd_kernel(
     const bf16_t* __restrict__ dx, const bf16_t* __restrict__ dx2, const bf16_t* __restrict__ y,
     const bf16_t* __restrict__ resid, const float* __restrict__ stats, int rows, int H,
@@ -169,12 +173,13 @@ __global__ __launch_bounds__(256) void residual_ln_bwd_kernel(
       }
     }
   }
-  flush_colsums(lds_acc, acc, H, lane, d_gamma, d_beta, d_bias);
+  flush_colsums<NIT>(lds_acc, acc, H, lane, d_gamma, d_beta, d_bias);
 }
 
 // ---------------------------------------------------------------------------------------------
 // embeddings: x = dropout(LN(word[id] + pos[s] + type[0]))
 // ---------------------------------------------------------------------------------------------
+template <int NIT>
 __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(
     const int64_t* __restrict__ ids, int rows, int S, int H, int vocab, const float* __restrict__ word,
     const float* __restrict__ pos, const float* __restrict__ type0, const float* __restrict__ gamma,
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(
                 *(const f32x4*)(pos + (size_t)s * H + c);
       }
     }
-    const LnStat st = row_stats(z, H, lane, eps);
+    const LnStat st = row_stats<NIT>(z, H, lane, eps);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int c = (lane + 64 * it) * 4;
@@ -212,6 +217,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(
   }
 }
 
+template <int NIT>
 __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(
     const int64_t* __restrict__ ids, int rows, int S, int H, int vocab, const float* __restrict__ word,
     const float* __restrict__ pos, const float* __restrict__ type0, const float* __restrict__ gamma,
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(
       }
     }
   }
-  flush_colsums(lds_acc, acc, H, lane, d_gamma, d_beta, d_type0);
+  flush_colsums<NIT>(lds_acc, acc, H, lane, d_gamma, d_beta, d_type0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -392,6 +398,14 @@ static bool hidden_ok(int H) { return H > 0 && H <= 1024 && (H % 8) == 0; }
 
 using namespace czc;
 
+#define LAUNCH_NIT(kern, H, grid, st, ...)                                                         \
+  do {                                                                                              \
+    if ((H) <= 256) hipLaunchKernelGGL(kern<1>, grid, dim3(256), 0, st, __VA_ARGS__);              \
+    else if ((H) <= 512) hipLaunchKernelGGL(kern<2>, grid, dim3(256), 0, st, __VA_ARGS__);         \
+    else if ((H) <= 768) hipLaunchKernelGGL(kern<3>, grid, dim3(256), 0, st, __VA_ARGS__);         \
+    else hipLaunchKernelGGL(kern<4>, grid, dim3(256), 0, st, __VA_ARGS__);                         \
+  } while (0)
+
 #define DROP_ARGS(p) \
   const uint32_t thr = (p) > 0.f ? czc_drop_thr(p) : 0u; \
   const float inv_keep = (p) > 0.f ? 1.0f / (1.0f - (p)) : 1.0f
@@ -402,8 +416,8 @@ extern "C" int czc_residual_ln_forward(const uint16_t* y, const uint16_t* resid,
   CZC_REQUIRE(hidden_ok(hidden), "czc_residual_ln_forward: hidden=%d must be a multiple of 8 and <= 1024", hidden);
   CZC_REQUIRE(rows > 0 && dropout_p >= 0.f && dropout_p < 1.f, "czc_residual_ln_forward: rows=%d p=%f", rows, dropout_p);
   DROP_ARGS(dropout_p);
-  hipLaunchKernelGGL(residual_ln_fwd_kernel, dim3(row_grid(rows)), dim3(256), 0, (hipStream_t)stream, y, resid, rows,
-                     hidden, gamma, beta, eps, thr, inv_keep, seed, site, x, stats);
+  LAUNCH_NIT(residual_ln_fwd_kernel, hidden, dim3(row_grid(rows)), (hipStream_t)stream, y, resid, rows, hidden, gamma, beta,
+             eps, thr, inv_keep, seed, site, x, stats);
   CZC_LAUNCH_CHECK();
   return CZC_OK;
 }
@@ -419,9 +433,8 @@ extern "C" int czc_residual_ln_backward(const uint16_t* dx, const uint16_t* dx2,
   CZC_REQUIRE(!(dropout_p > 0.f && dz_out == dy_out), "czc_residual_ln_backward: dy_out must differ from dz_out when p > 0");
   DROP_ARGS(dropout_p);
   int g = row_grid(rows);
-  if (g > 1024) g = 1024;
-  hipLaunchKernelGGL(residual_ln_bwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, dx, dx2, y, resid, stats, rows,
-                     hidden, gamma, thr, inv_keep, seed, site, dz_out, dy_out, d_gamma, d_beta, d_bias);
+  LAUNCH_NIT(residual_ln_bwd_kernel, hidden, dim3(g), (hipStream_t)stream, dx, dx2, y, resid, stats, rows, hidden, gamma, thr,
+             inv_keep, seed, site, dz_out, dy_out, d_gamma, d_beta, d_bias);
   CZC_LAUNCH_CHECK();
   return CZC_OK;
 }
@@ -434,8 +447,8 @@ extern "C" int czc_embed_ln_forward(const int64_t* ids, int batch, int seq, int 
   CZC_REQUIRE(batch > 0 && seq > 0 && vocab > 0, "czc_embed_ln_forward: batch=%d seq=%d vocab=%d", batch, seq, vocab);
   DROP_ARGS(dropout_p);
   const int rows = batch * seq;
-  hipLaunchKernelGGL(embed_ln_fwd_kernel, dim3(row_grid(rows)), dim3(256), 0, (hipStream_t)stream, ids, rows, seq,
-                     hidden, vocab, word, pos, type0, gamma, beta, eps, thr, inv_keep, seed, site, x, stats);
+  LAUNCH_NIT(embed_ln_fwd_kernel, hidden, dim3(row_grid(rows)), (hipStream_t)stream, ids, rows, seq, hidden, vocab, word, pos,
+             type0, gamma, beta, eps, thr, inv_keep, seed, site, x, stats);
   CZC_LAUNCH_CHECK();
   return CZC_OK;
 }
@@ -451,9 +464,8 @@ extern "C" int czc_embed_ln_backward(const int64_t* ids, int batch, int seq, int
   const int rows = batch * seq;
   int g = row_grid(rows);
   if (g > 1024) g = 1024;
-  hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, ids, rows, seq, hidden, vocab,
-                     word, pos, type0, gamma, stats, thr, inv_keep, seed, site, dx, d_word, d_pos, d_type0, d_gamma,
-                     d_beta);
+  LAUNCH_NIT(embed_ln_bwd_kernel, hidden, dim3(g), (hipStream_t)stream, ids, rows, seq, hidden, vocab, word, pos, type0,
+             gamma, stats, thr, inv_keep, seed, site, dx, d_word, d_pos, d_type0, d_gamma, d_beta);
   CZC_LAUNCH_CHECK();
   return CZC_OK;
 }

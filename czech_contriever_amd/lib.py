@@ -49,11 +49,12 @@ SIGNATURES = {
     "czc_clamp": (i32, [vp, i64, f32, f32, vp]),
     "czc_cast_bf16": (i32, [vp, vp, i64, vp]),
     "czc_gemm_bf16": (i32, [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, vp]),
+    "czc_gemm_set_tile": (i32, [i32]),
     "czc_probe_arm": (i32, [i32, i32, i32, i32, i32, i32, i32]),
     "czc_probe_read": (i32, [C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "czc_reduce_slabs": (i32, [vp, i32, i64, vp, i32, vp]),
     "czc_attention_forward": (i32, [vp, vp, i32, i32, i32, f32, u32, u32, vp, vp, vp]),
-    "czc_attention_backward": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32, u32, u32, vp, vp, vp]),
+    "czc_attention_backward": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32, u32, u32, vp, vp, vp, vp]),
     "czc_embed_ln_forward": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, f32, u32, u32, vp, vp, vp]),
     "czc_embed_ln_backward": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, u32, u32, vp, vp, vp, vp, vp, vp, vp]),
     "czc_residual_ln_forward": (i32, [vp, vp, i32, i32, vp, vp, f32, f32, u32, u32, vp, vp, vp]),

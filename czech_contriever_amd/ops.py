@@ -49,12 +49,12 @@ def attention_forward(qkv, mask, B, S, heads, p=0.0, seed=0, site=0):
     return ctx, lse
 
 
-def attention_backward(qkv, mask, ctx, dctx, lse, B, S, heads, p=0.0, seed=0, site=0):
+def attention_backward(qkv, mask, ctx, dctx, lse, B, S, heads, p=0.0, seed=0, site=0, d_bias=None):
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(B, heads, S, dtype=F32, device=qkv.device)
     L.check(_l().czc_attention_backward(L.ptr(qkv, BF16), L.ptr(mask), L.ptr(ctx, BF16), L.ptr(dctx, BF16),
                                         L.ptr(lse, F32), B, S, heads, p, seed, site, L.ptr(delta), L.ptr(dqkv),
-                                        L.stream_ptr()))
+                                        L.ptr(d_bias), L.stream_ptr()))
     return dqkv
 
 

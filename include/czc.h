@@ -185,6 +185,10 @@ int czc_gemm_bf16(int a_layout, int b_layout, int epilogue, int M, int N, int K,
                   void* C, int ldc, const float* bias, const uint16_t* aux, void* C2,
                   int splitk, czc_stream_t stream);
 
+/* Tile configuration used by every later GEMM launch that does not choose one itself:
+ * 0 = built-in choice, 1 = 256x256 tile (8 waves, 1 workgroup/CU), 2 = 128x128 (4 waves, 2 workgroups/CU) */
+int czc_gemm_set_tile(int cfg);
+
 /* Timing probe (bench only): records hipEvents on the launch stream around every czc GEMM launch whose
  * (layouts, epilogue, M, N, K) match, up to max_samples launches; max_samples <= 0 disarms.
  * czc_probe_read synchronises on the recorded events and returns their summed duration. */
@@ -200,11 +204,12 @@ int czc_reduce_slabs(const float* slabs, int nslabs, int64_t n, float* dst, int 
 int czc_attention_forward(const uint16_t* qkv, const uint8_t* mask, int batch, int seq, int heads,
                           float dropout_p, uint32_t seed, uint32_t site,
                           uint16_t* ctx, float* lse, czc_stream_t stream);
-/* dqkv bf16 [batch*seq, 3H];  delta f32 [batch, heads, seq] is scratch */
+/* dqkv bf16 [batch*seq, 3H];  delta f32 [batch, heads, seq] is scratch;  d_bias_qkv f32 [3H] (may be NULL)
+ * += column sums of dqkv = the bias gradient of the fused QKV projection */
 int czc_attention_backward(const uint16_t* qkv, const uint8_t* mask, const uint16_t* ctx,
                            const uint16_t* dctx, const float* lse, int batch, int seq, int heads,
                            float dropout_p, uint32_t seed, uint32_t site,
-                           float* delta, uint16_t* dqkv, czc_stream_t stream);
+                           float* delta, uint16_t* dqkv, float* d_bias_qkv, czc_stream_t stream);
 
 /* x = dropout(LN(word[ids] + pos[s] + type[0]))  bf16 [M,H];  stats f32 [M,2] = (mean, rstd) */
 int czc_embed_ln_forward(const int64_t* ids, int batch, int seq, int hidden, int vocab,

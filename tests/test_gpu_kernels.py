@@ -329,7 +329,9 @@ def test_attention_fwd_bwd(ops, B, S, nh, lengths):
     report("attn fwd", ctx, ref, 2e-2, 1e-2)
     dctx = rnd(B * S, H, seed=2, dtype=BF16)
     ref.backward(dctx.float())
-    dqkv = ops.attention_backward(qkv, mask, ctx, dctx, lse, B, S, nh)
+    dbias = torch.zeros(3 * H, device=dev())
+    dqkv = ops.attention_backward(qkv, mask, ctx, dctx, lse, B, S, nh, d_bias=dbias)
+    report("attn d_bias (column sums of dqkv)", dbias, qv.grad.sum(0), 2e-2 * math.sqrt(B * S), 2e-2)
     g = qv.grad.view(B, S, 3, H)
     d = dqkv.float().view(B, S, 3, H)
     # gradients of K/V rows at padded positions are exactly zero in both
