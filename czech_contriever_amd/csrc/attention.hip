@@ -89,7 +89,7 @@ __device__ __forceinline__ float keep16(uint32_t r, int odd, uint32_t thr, float
 struct AttnArgs {
   const bf16_t* qkv; const uint8_t* mask; const bf16_t* ctx; const bf16_t* dctx;
   const float* lse_in; float* lse; float* delta; bf16_t* out; bf16_t* dqkv;
-  float* dbias;  // [3H] bias gradient of the fused QKV projection (column sums of dqkv), may be null
+  float* dbias;  // per-workgroup partial column sums of dqkv: [gridDim.z * gridDim.x][3H] (null = not wanted)
   int B, S, nh, H;
   uint32_t thr, seed, site;
   float inv_keep;
@@ -315,17 +315,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
       tile_commit<64>(vr, vt[buf ^ 1], tid);
     }
   }
-  if (!active) return;
   if (a.dbias) {
-    // bias gradient of the Q projection: column sums over this wave's valid queries
+    // bias gradient of the Q projection: column sums over this wave's valid queries -> LDS -> one partial row
+    // per workgroup (no global atomics: 2048 adds per address would serialise at the memory side)
+    float* red = (float*)kt[0];
+    __syncthreads();
+    if (tid < 64) red[tid] = 0.f;
+    __syncthreads();
+    if (active) {
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float v = half_sum(qvalid ? dq[dt][i] * 0.125f : 0.f);
-        if (r == 0) unsafeAtomicAdd(a.dbias + hh * 64 + 32 * dt + (i & 3) + 8 * (i >> 2) + 4 * h, v);
-      }
+        for (int i = 0; i < 16; ++i) {
+          const float v = half_sum(qvalid ? dq[dt][i] * 0.125f : 0.f);
+          if (r == 0) atomicAdd(&red[32 * dt + (i & 3) + 8 * (i >> 2) + 4 * h], v);
+        }
+    }
+    __syncthreads();
+    if (tid < 64) a.dbias[(size_t)(blockIdx.z * gridDim.x + blockIdx.x) * H3 + hh * 64 + tid] = red[tid];
   }
+  if (!active) return;
   if (!qvalid) return;
   bf16_t* dst = a.dqkv + ((size_t)b * S + q0 + r) * H3 + hh * 64;
 #pragma unroll
@@ -438,18 +447,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
     }
     if (more) commit(buf ^ 1);
   }
-  if (!active) return;
   if (a.dbias) {
+    float* red = (float*)qt[0];   // [2][64]: K then V
+    __syncthreads();
+    if (tid < 128) red[tid] = 0.f;
+    __syncthreads();
+    if (active) {
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int d = hh * 64 + 32 * dt + (i & 3) + 8 * (i >> 2) + 4 * h;
-        const float vk = half_sum(kvalid ? dk[dt][i] * 0.125f : 0.f);
-        const float vv = half_sum(kvalid ? dv[dt][i] : 0.f);
-        if (r == 0) { unsafeAtomicAdd(a.dbias + a.H + d, vk); unsafeAtomicAdd(a.dbias + 2 * a.H + d, vv); }
-      }
+        for (int i = 0; i < 16; ++i) {
+          const int d = 32 * dt + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const float vk = half_sum(kvalid ? dk[dt][i] * 0.125f : 0.f);
+          const float vv = half_sum(kvalid ? dv[dt][i] : 0.f);
+          if (r == 0) { atomicAdd(&red[d], vk); atomicAdd(&red[64 + d], vv); }
+        }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      float* row = a.dbias + (size_t)(blockIdx.z * gridDim.x + blockIdx.x) * H3;
+      row[(tid < 64 ? a.H : 2 * a.H) + hh * 64 + (tid & 63)] = red[tid];
+    }
   }
+  if (!active) return;
   if (!kvalid) return;
   bf16_t* dstk = a.dqkv + ((size_t)b * S + k0 + r) * H3 + a.H + hh * 64;
   bf16_t* dstv = dstk + a.H;
@@ -478,6 +498,10 @@ static int attn_check(const char* who, int B, int S, int nh, float p) {
 
 using namespace czc;
 
+extern "C" int64_t czc_attention_bias_scratch_floats(int batch, int seq, int heads) {
+  return (int64_t)batch * ceil_div(seq, 128) * 3 * heads * 64;
+}
+
 extern "C" int czc_attention_forward(const uint16_t* qkv, const uint8_t* mask, int batch, int seq, int heads,
                                      float dropout_p, uint32_t seed, uint32_t site, uint16_t* ctx, float* lse,
                                      czc_stream_t stream) {
@@ -498,10 +522,11 @@ extern "C" int czc_attention_forward(const uint16_t* qkv, const uint8_t* mask, i
 extern "C" int czc_attention_backward(const uint16_t* qkv, const uint8_t* mask, const uint16_t* ctx,
                                       const uint16_t* dctx, const float* lse, int batch, int seq, int heads,
                                       float dropout_p, uint32_t seed, uint32_t site, float* delta, uint16_t* dqkv,
-                                      float* d_bias_qkv, czc_stream_t stream) {
+                                      float* d_bias_qkv, float* partials, czc_stream_t stream) {
   if (int rc = attn_check("czc_attention_backward", batch, seq, heads, dropout_p)) return rc;
   AttnArgs a{};
-  a.qkv = qkv; a.mask = mask; a.ctx = ctx; a.dctx = dctx; a.lse_in = lse; a.delta = delta; a.dqkv = dqkv; a.dbias = d_bias_qkv;
+  a.qkv = qkv; a.mask = mask; a.ctx = ctx; a.dctx = dctx; a.lse_in = lse; a.delta = delta; a.dqkv = dqkv; a.dbias = d_bias_qkv ? partials : nullptr;
+  CZC_REQUIRE(!d_bias_qkv || partials, "czc_attention_backward: d_bias_qkv needs the partials scratch");
   a.B = batch; a.S = seq; a.nh = heads; a.H = heads * 64;
   a.thr = dropout_p > 0.f ? czc_drop_thr(dropout_p) : 0u;
   a.inv_keep = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f;
@@ -516,5 +541,6 @@ extern "C" int czc_attention_backward(const uint16_t* qkv, const uint8_t* mask, 
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, grid, dim3(256), 0, st, a);
   }
   CZC_LAUNCH_CHECK();
+  if (d_bias_qkv) return czc_reduce_partials(partials, batch * (int)grid.x, 3 * a.H, 3 * a.H, d_bias_qkv, stream);
   return CZC_OK;
 }

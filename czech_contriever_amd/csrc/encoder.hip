@@ -103,7 +103,7 @@ static EncLayout enc_layout(const czc_bert_shape* s, int B, int S, int save) {
   return e;
 }
 
-struct BwdLayout { int64_t g0, z, y, x1, c, q3, u, delta, slabs, total; int64_t slab_bytes; };
+struct BwdLayout { int64_t g0, z, y, x1, c, q3, u, delta, part, slabs, total; int64_t slab_bytes; };
 static int dw_splits(int Mo, int No, int64_t Kred) {
   const int tiles = ceil_div(Mo, 256) * ceil_div(No, 256);
   int sp = 256 / tiles;
@@ -120,6 +120,15 @@ static BwdLayout bwd_layout(const czc_bert_shape* s, int B, int S) {
   b.g0 = take(M * H * 2); b.z = take(M * H * 2); b.y = take(M * H * 2); b.x1 = take(M * H * 2);
   b.c = take(M * H * 2); b.q3 = take(M * 3 * H * 2); b.u = take(M * I * 2);
   b.delta = take((int64_t)B * s->num_heads * S * 4);
+  {
+    // per-workgroup partial column sums: LN kernels (2048 x 3H), attention QKV bias, dGELU bias (tiles_m*2 x I)
+    int64_t pf = czc_colsum_scratch_floats((int)H);
+    const int64_t af = czc_attention_bias_scratch_floats(B, S, s->num_heads);
+    const int64_t gf = (int64_t)ceil_div64(M, 256) * 2 * I;
+    if (af > pf) pf = af;
+    if (gf > pf) pf = gf;
+    b.part = take(pf * 4);
+  }
   int64_t sb = 0;
   auto need = [&](int Mo, int No) { int64_t v = (int64_t)dw_splits(Mo, No, M) * Mo * No * 4; if (v > sb) sb = v; };
   need(3 * H, H); need(H, H); need(I, H); need(H, I);
@@ -211,8 +220,10 @@ extern "C" int czc_encoder_backward(const czc_bert_shape* s, const float* params
                                     const int64_t* ids, const uint8_t* mask, int batch, int seq, int pooling,
                                     int normalize, int training, uint32_t seed, void* workspace,
                                     int64_t workspace_bytes, void* scratch, int64_t scratch_bytes, const float* d_emb,
-                                    float* grads_f32, int accumulate, czc_stream_t stream) {
+                                    float* grads_f32, int accumulate, int layer_hi, int layer_lo, czc_stream_t stream) {
   RC(shape_check("czc_encoder_backward", s));
+  CZC_REQUIRE(0 <= layer_lo && layer_lo < layer_hi && layer_hi <= s->num_layers,
+              "czc_encoder_backward: layer range [%d, %d) outside [0, %d)", layer_lo, layer_hi, s->num_layers);
   CZC_REQUIRE(batch > 0 && seq > 0 && seq <= 512 && s->num_layers <= 64, "czc_encoder_backward: batch=%d seq=%d", batch, seq);
   CZC_REQUIRE(params_f32 && params_bf16 && ids && mask && d_emb && grads_f32, "czc_encoder_backward: null argument");
   const EncLayout e = enc_layout(s, batch, seq, 1);
@@ -234,13 +245,15 @@ extern "C" int czc_encoder_backward(const czc_bert_shape* s, const float* params
 #define GF(kind, l) (G + param_off(pl, kind, l))
 #define SBUF(off) ((uint16_t*)(sc + (off)))
 
-  if (!accumulate) {
+  const bool first = layer_hi == L, last = layer_lo == 0;
+  if (!accumulate && first) {
     // matrices are overwritten by the slab reduction; vectors and embeddings are accumulated by atomics
     CZC_HIP(hipMemsetAsync(G + pl.regionA, 0, (size_t)(pl.total - pl.regionA) * 4, st));
   }
   uint16_t* g0 = SBUF(bl.g0); uint16_t* Z = SBUF(bl.z); uint16_t* Y = ph > 0.f ? SBUF(bl.y) : Z;
   uint16_t* X1 = SBUF(bl.x1); uint16_t* C = SBUF(bl.c); uint16_t* Q3 = SBUF(bl.q3); uint16_t* U = SBUF(bl.u);
   float* delta = (float*)(sc + bl.delta);
+  float* part = (float*)(sc + bl.part);
   float* slabs = (float*)(sc + bl.slabs);
 
   auto dweight = [&](int Mo, int No, const uint16_t* dY, int ldy, const uint16_t* X, int ldx, float* dst) -> int {
@@ -249,28 +262,31 @@ extern "C" int czc_encoder_backward(const czc_bert_shape* s, const float* params
     return czc_reduce_slabs(slabs, sp, (int64_t)Mo * No, dst, accumulate, stream);
   };
 
-  RC(czc_pool_backward(d_emb, FBUF(e.raw), mask, batch, seq, H, pooling, normalize, g0, stream));
-  for (int l = L - 1; l >= 0; --l) {
+  // the gradient w.r.t. the input of layer `layer_hi` stays in scratch (g0) between ranged calls
+  if (first) RC(czc_pool_backward(d_emb, FBUF(e.raw), mask, batch, seq, H, pooling, normalize, g0, stream));
+  for (int l = layer_hi - 1; l >= layer_lo; --l) {
     const LayerWs& w = e.layer[l];
     // x[l+1] = LN(drop(y2) + x1)
     RC(czc_residual_ln_backward(g0, nullptr, BUF(w.y2), BUF(w.x1), FBUF(w.st2), M, H, PF(CZC_P_LN2W, l), ph, seed,
-                                SITE_H2(l), Z, Y, GF(CZC_P_LN2W, l), GF(CZC_P_LN2B, l), GF(CZC_P_B2, l), stream));
+                                SITE_H2(l), Z, Y, GF(CZC_P_LN2W, l), GF(CZC_P_LN2B, l), GF(CZC_P_B2, l), part, stream));
     RC(dweight(H, I, Y, H, BUF(w.hact), I, GF(CZC_P_W2, l)));
-    RC(gemm(0, 1, EPI_DGELU, M, I, H, Y, H, WB(CZC_P_W2, l), I, U, I, nullptr, BUF(w.u), nullptr, 1, st, GF(CZC_P_B1, l)));
+    RC(gemm(0, 1, EPI_DGELU, M, I, H, Y, H, WB(CZC_P_W2, l), I, U, I, nullptr, BUF(w.u), nullptr, 1, st, part));
+    RC(czc_reduce_partials(part, ceil_div(M, 256) * 2, I, I, GF(CZC_P_B1, l), stream));
     RC(dweight(I, H, U, I, BUF(w.x1), H, GF(CZC_P_W1, l)));
     RC(gemm(0, 1, EPI_ADD, M, H, I, U, I, WB(CZC_P_W1, l), H, X1, H, nullptr, Z, nullptr, 1, st));
     // x1 = LN(drop(y1) + x[l])
     RC(czc_residual_ln_backward(X1, nullptr, BUF(w.y1), BUF(e.x[l]), FBUF(w.st1), M, H, PF(CZC_P_LN1W, l), ph, seed,
-                                SITE_H1(l), Z, Y, GF(CZC_P_LN1W, l), GF(CZC_P_LN1B, l), GF(CZC_P_BO, l), stream));
+                                SITE_H1(l), Z, Y, GF(CZC_P_LN1W, l), GF(CZC_P_LN1B, l), GF(CZC_P_BO, l), part, stream));
     RC(dweight(H, H, Y, H, BUF(w.ctx), H, GF(CZC_P_WO, l)));
     RC(gemm(0, 1, EPI_STORE, M, H, H, Y, H, WB(CZC_P_WO, l), H, C, H, nullptr, nullptr, nullptr, 1, st));
     RC(czc_attention_backward(BUF(w.qkv), mask, BUF(w.ctx), C, FBUF(w.lse), batch, seq, nh, pa, seed, SITE_ATTN(l), delta, Q3,
-                              GF(CZC_P_BQKV, l), stream));
+                              GF(CZC_P_BQKV, l), part, stream));
     RC(dweight(3 * H, H, Q3, 3 * H, BUF(e.x[l]), H, GF(CZC_P_WQKV, l)));
     RC(gemm(0, 1, EPI_ADD, M, H, 3 * H, Q3, 3 * H, WB(CZC_P_WQKV, l), H, g0, H, nullptr, Z, nullptr, 1, st));
   }
+  if (last)
   RC(czc_embed_ln_backward(ids, batch, seq, H, s->vocab_size, PF(CZC_P_WORD, 0), PF(CZC_P_POS, 0), PF(CZC_P_TYPE, 0),
                            PF(CZC_P_ELNW, 0), FBUF(e.st0), ph, seed, SITE_EMB, g0, GF(CZC_P_WORD, 0), GF(CZC_P_POS, 0),
-                           GF(CZC_P_TYPE, 0), GF(CZC_P_ELNW, 0), GF(CZC_P_ELNB, 0), stream));
+                           GF(CZC_P_TYPE, 0), GF(CZC_P_ELNW, 0), GF(CZC_P_ELNB, 0), part, stream));
   return CZC_OK;
 }

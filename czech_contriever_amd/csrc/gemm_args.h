@@ -10,7 +10,7 @@ struct GemmArgs {
   const float* bias; const bf16_t* aux;
   const float* rowv;     // per-row vector (head: lse)
   float* part;           // head partials [3][tilesN][M]
-  float* colsum;         // optional [N]: += column sums of C (DGELU epilogue: bias gradient)
+  float* colsum;         // optional [tiles_m * WM][N] per-wave-row partial column sums of C (DGELU epilogue)
   int M, N, K;
   int lda, ldb, ldc;
   int tiles_m, tiles_n;

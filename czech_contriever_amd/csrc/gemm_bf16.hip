@@ -378,10 +378,12 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
       t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
       csum[j] = t;
     }
+    // one partial row per (M-tile, wave row): colsum[(tm * WM + wm)][N], written whole (no atomics)
     const int n = col0 + wn * 64 + (lane & 7) * 8;
     if ((lane >> 3) == 0 && n < a.N) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) unsafeAtomicAdd(a.colsum + n + j, csum[j]);
+      float* row = a.colsum + (size_t)(tm * CF::WM + wm) * a.N + n;
+      *(f32x4*)row = (f32x4){csum[0], csum[1], csum[2], csum[3]};
+      *(f32x4*)(row + 4) = (f32x4){csum[4], csum[5], csum[6], csum[7]};
     }
   }
 }
@@ -410,7 +412,7 @@ static int launch_cfg(GemmArgs a, int splits, hipStream_t st) {
 template <int AL, int BL, int EPI>
 static int launch(const GemmArgs& a, int splits, hipStream_t st) {
   int cfg = a.cfg ? a.cfg : g_tile_override;
-  if (EPI == EPI_LSE || EPI == EPI_SOFTGRAD) cfg = 1;
+  if (EPI == EPI_LSE || EPI == EPI_SOFTGRAD || a.colsum) cfg = 1;  // partial-sum rows are laid out for 256-row tiles
   if (cfg == 0) cfg = 1;
   if (cfg == 2) return launch_cfg<AL, BL, EPI, CfgSmall>(a, splits, st);
   return launch_cfg<AL, BL, EPI, CfgBig>(a, splits, st);

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void residual_ln_fwd_kernel(
 // ---------------------------------------------------------------------------------------------
 template <int NIT>
 __device__ __forceinline__ void flush_colsums(float* lds_acc, const f32x4 (&acc)[3][NIT], int H, int lane,
-                                              float* d0, float* d1, float* d2) {
+                                              float* d0, float* d1, float* d2, float* part = nullptr) {
   // lds_acc [3][1024] zeroed by the caller; waves add their lane-private partial sums
 #pragma unroll
   for (int s = 0; s < 3; ++s)
@@ -107,6 +107,17 @@ __device__ __forceinline__ void flush_colsums(float* lds_acc, const f32x4 (&acc)
       }
     }
   __syncthreads();
+  if (part) {
+    // one row of per-workgroup partial sums; reduce_partials_kernel folds the rows afterwards.  (Thousands of
+    // workgroups adding to the same few hundred addresses serialise at the memory side: ~0.1 us per add.)
+    float* row = part + (size_t)blockIdx.x * 3 * H;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+      row[c] = lds_acc[c];
+      row[H + c] = lds_acc[1024 + c];
+      row[2 * H + c] = lds_acc[2048 + c];
+    }
+    return;
+  }
   for (int c = threadIdx.x; c < H; c += blockDim.x) {
     if (d0) unsafeAtomicAdd(d0 + c, lds_acc[c]);
     if (d1) unsafeAtomicAdd(d1 + c, lds_acc[1024 + c]);
@@ -114,12 +125,52 @@ __device__ __forceinline__ void flush_colsums(float* lds_acc, const f32x4 (&acc)
   }
 }
 
+// dst[c] += sum_r part[r * row_stride + c]   for c < ncols; blockIdx.y splits the rows (<= 32-deep atomic chains)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nrows, int row_stride,
+                                                              int ncols, float* dst) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncols) return;
+  float s = 0.f;
+  for (int r = blockIdx.y; r < nrows; r += gridDim.y) s += part[(size_t)r * row_stride + c];
+  unsafeAtomicAdd(dst + c, s);
+}
+// LN kernels: rows of [3][H] partials -> three destinations in one launch
+__global__ __launch_bounds__(256) void reduce_partials3_kernel(const float* __restrict__ part, int nrows, int H, float* d0,
+                                                               float* d1, float* d2) {
+  __shared__ float red[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;          // column in [0, 3H)
+  float s = 0.f;
+  if (c < 3 * H)
+    for (int r = blockIdx.y * 4 + ry; r < nrows; r += gridDim.y * 4) s += part[(size_t)r * 3 * H + c];
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && c < 3 * H) {
+    s = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+    const int seg = c / H, cc = c - seg * H;
+    float* d = seg == 0 ? d0 : (seg == 1 ? d1 : d2);
+    if (d) unsafeAtomicAdd(d + cc, s);
+  }
+}
+static void launch_reduce_partials3(const float* part, int nrows, int H, float* d0, float* d1, float* d2, hipStream_t st) {
+  int chunks = nrows / 32;
+  if (chunks < 1) chunks = 1;
+  if (chunks > 16) chunks = 16;
+  hipLaunchKernelGGL(reduce_partials3_kernel, dim3(ceil_div(3 * H, 64), chunks), dim3(256), 0, st, part, nrows, H, d0, d1, d2);
+}
+static void launch_reduce_partials(const float* part, int nrows, int row_stride, int ncols, float* dst, hipStream_t st) {
+  if (!dst) return;
+  const int chunks = nrows < 32 ? nrows : 32;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(ncols, 256), chunks), dim3(256), 0, st, part, nrows, row_stride,
+                     ncols, dst);
+}
+
 template <int NIT>
 __global__ __launch_bounds__(256) void residual_ln_bwd_kernel(
     const bf16_t* __restrict__ dx, const bf16_t* __restrict__ dx2, const bf16_t* __restrict__ y,
     const bf16_t* __restrict__ resid, const float* __restrict__ stats, int rows, int H,
     const float* __restrict__ gamma, uint32_t thr, float inv_keep, uint32_t seed, uint32_t site,
-    bf16_t* __restrict__ dz_out, bf16_t* __restrict__ dy_out, float* d_gamma, float* d_beta, float* d_bias) {
+    bf16_t* __restrict__ dz_out, bf16_t* __restrict__ dy_out, float* d_gamma, float* d_beta, float* d_bias, float* part) {
   __shared__ float lds_acc[3 * 1024];
   for (int i = threadIdx.x; i < 3 * 1024; i += blockDim.x) lds_acc[i] = 0.f;
   __syncthreads();
@@ -173,7 +224,7 @@ __global__ __launch_bounds__(256) void residual_ln_bwd_kernel(
       }
     }
   }
-  flush_colsums<NIT>(lds_acc, acc, H, lane, d_gamma, d_beta, d_bias);
+  flush_colsums<NIT>(lds_acc, acc, H, lane, d_gamma, d_beta, d_bias, part);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -222,7 +273,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(
     const int64_t* __restrict__ ids, int rows, int S, int H, int vocab, const float* __restrict__ word,
     const float* __restrict__ pos, const float* __restrict__ type0, const float* __restrict__ gamma,
     const float* __restrict__ stats, uint32_t thr, float inv_keep, uint32_t seed, uint32_t site,
-    const bf16_t* __restrict__ dx, float* d_word, float* d_pos, float* d_type0, float* d_gamma, float* d_beta) {
+    const bf16_t* __restrict__ dx, float* d_word, float* d_pos, float* d_type0, float* d_gamma, float* d_beta, float* part) {
   __shared__ float lds_acc[3 * 1024];
   for (int i = threadIdx.x; i < 3 * 1024; i += blockDim.x) lds_acc[i] = 0.f;
   __syncthreads();
@@ -279,7 +330,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(
       }
     }
   }
-  flush_colsums<NIT>(lds_acc, acc, H, lane, d_gamma, d_beta, d_type0);
+  flush_colsums<NIT>(lds_acc, acc, H, lane, d_gamma, d_beta, d_type0, part);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -426,7 +477,7 @@ extern "C" int czc_residual_ln_backward(const uint16_t* dx, const uint16_t* dx2,
                                         const uint16_t* resid, const float* stats, int rows, int hidden,
                                         const float* gamma, float dropout_p, uint32_t seed, uint32_t site,
                                         uint16_t* dz_out, uint16_t* dy_out, float* d_gamma, float* d_beta,
-                                        float* d_bias, czc_stream_t stream) {
+                                        float* d_bias, float* partials, czc_stream_t stream) {
   CZC_REQUIRE(hidden_ok(hidden), "czc_residual_ln_backward: hidden=%d must be a multiple of 8 and <= 1024", hidden);
   CZC_REQUIRE(rows > 0 && dropout_p >= 0.f && dropout_p < 1.f, "czc_residual_ln_backward: rows=%d p=%f", rows, dropout_p);
   CZC_REQUIRE(dz_out && dy_out, "czc_residual_ln_backward: outputs missing");
@@ -434,7 +485,8 @@ extern "C" int czc_residual_ln_backward(const uint16_t* dx, const uint16_t* dx2,
   DROP_ARGS(dropout_p);
   int g = row_grid(rows);
   LAUNCH_NIT(residual_ln_bwd_kernel, hidden, dim3(g), (hipStream_t)stream, dx, dx2, y, resid, stats, rows, hidden, gamma, thr,
-             inv_keep, seed, site, dz_out, dy_out, d_gamma, d_beta, d_bias);
+             inv_keep, seed, site, dz_out, dy_out, d_gamma, d_beta, d_bias, partials);
+  if (partials) launch_reduce_partials3(partials, g, hidden, d_gamma, d_beta, d_bias, (hipStream_t)stream);
   CZC_LAUNCH_CHECK();
   return CZC_OK;
 }
@@ -456,7 +508,7 @@ extern "C" int czc_embed_ln_forward(const int64_t* ids, int batch, int seq, int 
 extern "C" int czc_embed_ln_backward(const int64_t* ids, int batch, int seq, int hidden, int vocab, const float* word,
                                      const float* pos, const float* type0, const float* gamma, const float* stats,
                                      float dropout_p, uint32_t seed, uint32_t site, const uint16_t* dx, float* d_word,
-                                     float* d_pos, float* d_type0, float* d_gamma, float* d_beta,
+                                     float* d_pos, float* d_type0, float* d_gamma, float* d_beta, float* partials,
                                      czc_stream_t stream) {
   CZC_REQUIRE(hidden_ok(hidden), "czc_embed_ln_backward: hidden=%d must be a multiple of 8 and <= 1024", hidden);
   CZC_REQUIRE(batch > 0 && seq > 0 && vocab > 0, "czc_embed_ln_backward: batch=%d seq=%d vocab=%d", batch, seq, vocab);
@@ -465,7 +517,8 @@ extern "C" int czc_embed_ln_backward(const int64_t* ids, int batch, int seq, int
   int g = row_grid(rows);
   if (g > 1024) g = 1024;
   LAUNCH_NIT(embed_ln_bwd_kernel, hidden, dim3(g), (hipStream_t)stream, ids, rows, seq, hidden, vocab, word, pos, type0,
-             gamma, stats, thr, inv_keep, seed, site, dx, d_word, d_pos, d_type0, d_gamma, d_beta);
+             gamma, stats, thr, inv_keep, seed, site, dx, d_word, d_pos, d_type0, d_gamma, d_beta, partials);
+  if (partials) launch_reduce_partials3(partials, g, hidden, d_gamma, d_beta, d_type0, (hipStream_t)stream);
   CZC_LAUNCH_CHECK();
   return CZC_OK;
 }
@@ -488,6 +541,16 @@ extern "C" int czc_pool_backward(const float* d_emb, const float* raw, const uin
   CZC_REQUIRE(!normalize || raw, "czc_pool_backward: normalize needs the raw embedding");
   hipLaunchKernelGGL(pool_bwd_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, d_emb, raw, mask, seq, hidden,
                      pooling, normalize, dx);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
+extern "C" int64_t czc_colsum_scratch_floats(int hidden) { return (int64_t)2048 * 3 * hidden; }
+
+extern "C" int czc_reduce_partials(const float* partials, int nrows, int row_stride, int ncols, float* dst,
+                                   czc_stream_t stream) {
+  CZC_REQUIRE(partials && dst && nrows > 0 && ncols > 0 && row_stride >= ncols, "czc_reduce_partials: bad arguments");
+  launch_reduce_partials(partials, nrows, row_stride, ncols, dst, (hipStream_t)stream);
   CZC_LAUNCH_CHECK();
   return CZC_OK;
 }

@@ -98,6 +98,8 @@ class FlatBertEncoder(nn.Module):
         self._call = 0
         self._anchor = None
         self._post_backward = []  # callables(enc) run right after the backward has been enqueued
+        self._range_hooks = []    # callables(enc, elem_lo, elem_hi): a gradient range [lo, hi) of the flat array is final
+        self.backward_chunk_layers = 0   # > 0: issue the backward in ranges of this many layers (for comm overlap)
         self._plist: List[nn.Parameter] = []
         for name, shape, off in self._table:
             node = self
@@ -248,10 +250,23 @@ class FlatBertEncoder(nn.Module):
         sc = self._bwd_scratch(B, S)
         fresh = any(p.grad is None for p in self._plist if p.requires_grad)
         g = self.flat_grads()
-        L.check(L.load().czc_encoder_backward(
-            C.byref(self._shape), self._flat.data_ptr(), self.mirror().data_ptr(), ids.data_ptr(), mask.data_ptr(),
-            B, S, self._pool_code(), int(normalize), int(training), seed, ws.data_ptr(), ws.numel(), sc.data_ptr(),
-            sc.numel(), d_emb.contiguous().data_ptr(), g.data_ptr(), 0 if fresh else 1, L.stream_ptr()))
+        nl = self._shape.num_layers
+        step = self.backward_chunk_layers if (self.backward_chunk_layers > 0 and self._range_hooks) else nl
+        la = self._n_mat // nl                       # matrix-region elements per layer
+        d_emb = d_emb.contiguous()
+        mirror = self.mirror()
+        hi = nl
+        while hi > 0:
+            lo = max(0, hi - step)
+            L.check(L.load().czc_encoder_backward(
+                C.byref(self._shape), self._flat.data_ptr(), mirror.data_ptr(), ids.data_ptr(), mask.data_ptr(),
+                B, S, self._pool_code(), int(normalize), int(training), seed, ws.data_ptr(), ws.numel(), sc.data_ptr(),
+                sc.numel(), d_emb.data_ptr(), g.data_ptr(), 0 if fresh else 1, hi, lo, L.stream_ptr()))
+            for hook in self._range_hooks:
+                hook(self, lo * la, hi * la)          # these layers' weight matrices are final
+            hi = lo
+        for hook in self._range_hooks:
+            hook(self, self._n_mat, self._n)          # vectors (biases, LayerNorm) and embeddings
         if fresh:
             for (name, shape, off), p in zip(self._table, self._plist):
                 if p.requires_grad:

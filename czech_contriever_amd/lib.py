@@ -36,7 +36,7 @@ SIGNATURES = {
     "czc_encoder_workspace_bytes": (i64, [SP, i32, i32, i32]),
     "czc_encoder_backward_scratch_bytes": (i64, [SP, i32, i32]),
     "czc_encoder_forward": (i32, [SP, vp, vp, vp, vp, i32, i32, i32, i32, i32, u32, i32, vp, i64, vp, vp]),
-    "czc_encoder_backward": (i32, [SP, vp, vp, vp, vp, i32, i32, i32, i32, i32, u32, vp, i64, vp, i64, vp, vp, i32, vp]),
+    "czc_encoder_backward": (i32, [SP, vp, vp, vp, vp, i32, i32, i32, i32, i32, u32, vp, i64, vp, i64, vp, vp, i32, i32, i32, vp]),
     "czc_infonce_workspace_bytes": (i64, [i32, i32, i32]),
     "czc_infonce_forward": (i32, [vp, vp, vp, i32, i32, i32, f32, f32, vp, i64, vp, vp, vp]),
     "czc_infonce_backward": (i32, [vp, vp, vp, i32, i32, i32, f32, f32, vp, f32, vp, i64, vp, vp]),
@@ -54,11 +54,14 @@ SIGNATURES = {
     "czc_probe_read": (i32, [C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "czc_reduce_slabs": (i32, [vp, i32, i64, vp, i32, vp]),
     "czc_attention_forward": (i32, [vp, vp, i32, i32, i32, f32, u32, u32, vp, vp, vp]),
-    "czc_attention_backward": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32, u32, u32, vp, vp, vp, vp]),
+    "czc_attention_backward": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32, u32, u32, vp, vp, vp, vp, vp]),
+    "czc_attention_bias_scratch_floats": (i64, [i32, i32, i32]),
+    "czc_colsum_scratch_floats": (i64, [i32]),
+    "czc_reduce_partials": (i32, [vp, i32, i32, i32, vp, vp]),
     "czc_embed_ln_forward": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, f32, u32, u32, vp, vp, vp]),
-    "czc_embed_ln_backward": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, u32, u32, vp, vp, vp, vp, vp, vp, vp]),
+    "czc_embed_ln_backward": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "czc_residual_ln_forward": (i32, [vp, vp, i32, i32, vp, vp, f32, f32, u32, u32, vp, vp, vp]),
-    "czc_residual_ln_backward": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, f32, u32, u32, vp, vp, vp, vp, vp, vp]),
+    "czc_residual_ln_backward": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, f32, u32, u32, vp, vp, vp, vp, vp, vp, vp]),
     "czc_colsum_bf16": (i32, [vp, i32, i32, i32, vp, vp]),
     "czc_pool_forward": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     "czc_pool_backward": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),

@@ -52,9 +52,12 @@ def attention_forward(qkv, mask, B, S, heads, p=0.0, seed=0, site=0):
 def attention_backward(qkv, mask, ctx, dctx, lse, B, S, heads, p=0.0, seed=0, site=0, d_bias=None):
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(B, heads, S, dtype=F32, device=qkv.device)
+    part = None
+    if d_bias is not None:
+        part = torch.empty(_l().czc_attention_bias_scratch_floats(B, S, heads), dtype=F32, device=qkv.device)
     L.check(_l().czc_attention_backward(L.ptr(qkv, BF16), L.ptr(mask), L.ptr(ctx, BF16), L.ptr(dctx, BF16),
                                         L.ptr(lse, F32), B, S, heads, p, seed, site, L.ptr(delta), L.ptr(dqkv),
-                                        L.ptr(d_bias), L.stream_ptr()))
+                                        L.ptr(d_bias), L.ptr(part), L.stream_ptr()))
     return dqkv
 
 
@@ -67,13 +70,15 @@ def residual_ln_forward(y, resid, gamma, beta, eps, p=0.0, seed=0, site=0):
     return x, stats
 
 
-def residual_ln_backward(dx, dx2, y, resid, stats, gamma, d_gamma, d_beta, d_bias, p=0.0, seed=0, site=0):
+def residual_ln_backward(dx, dx2, y, resid, stats, gamma, d_gamma, d_beta, d_bias, p=0.0, seed=0, site=0,
+                         use_partials=True):
     rows, H = y.shape
+    part = torch.empty(_l().czc_colsum_scratch_floats(H), dtype=F32, device=y.device) if use_partials else None
     dz = torch.empty_like(y)
     dy = torch.empty_like(y) if p > 0 else dz
     L.check(_l().czc_residual_ln_backward(L.ptr(dx, BF16), L.ptr(dx2), L.ptr(y, BF16), L.ptr(resid, BF16),
                                           L.ptr(stats, F32), rows, H, L.ptr(gamma, F32), p, seed, site, L.ptr(dz),
-                                          L.ptr(dy), L.ptr(d_gamma), L.ptr(d_beta), L.ptr(d_bias), L.stream_ptr()))
+                                          L.ptr(dy), L.ptr(d_gamma), L.ptr(d_beta), L.ptr(d_bias), L.ptr(part), L.stream_ptr()))
     return dz, dy
 
 
@@ -89,13 +94,14 @@ def embed_ln_forward(ids, word, pos, type0, gamma, beta, eps, p=0.0, seed=0, sit
 
 
 def embed_ln_backward(ids, word, pos, type0, gamma, stats, dx, d_word, d_pos, d_type0, d_gamma, d_beta, p=0.0,
-                      seed=0, site=0):
+                      seed=0, site=0, use_partials=True):
     B, S = ids.shape
     V, H = word.shape
+    part = torch.empty(_l().czc_colsum_scratch_floats(H), dtype=F32, device=ids.device) if use_partials else None
     L.check(_l().czc_embed_ln_backward(L.ptr(ids, torch.int64), B, S, H, V, L.ptr(word, F32), L.ptr(pos, F32),
                                        L.ptr(type0, F32), L.ptr(gamma, F32), L.ptr(stats, F32), p, seed, site,
                                        L.ptr(dx, BF16), L.ptr(d_word), L.ptr(d_pos), L.ptr(d_type0), L.ptr(d_gamma),
-                                       L.ptr(d_beta), L.stream_ptr()))
+                                       L.ptr(d_beta), L.ptr(part), L.stream_ptr()))
 
 
 def pool_forward(x, mask, B, S, pooling, normalize):

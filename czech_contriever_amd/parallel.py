@@ -3,9 +3,10 @@
 Replaces torch DDP at train.py:483-488 of the reference.  DDP cannot be used here: parameter
 gradients are written by libczc straight into one flat fp32 array, not through autograd hooks.
 What this wrapper does instead, per micro-step:
-  * gradient mean all-reduce of the WHOLE flat gradient array as one collective (435.6 MB fp32 at
-    bert-base), launched on a side stream the moment the encoder backward has been enqueued;
-    the optimizer waits on its event.  (The reference all-reduces on every micro-step as well:
+  * gradient mean all-reduce of the flat gradient array in 5 collectives on a side stream: the encoder
+    backward is issued in ranges of 3 layers (top first); as soon as a range has been enqueued its weight-matrix
+    gradients (one contiguous 85 MB slice of the flat array) are averaged while the next range computes; the
+    vectors + embeddings tail (96 MB) goes last.  The optimizer waits on the last event.  (The reference all-reduces on every micro-step as well:
     it never enters no_sync(), train.py:263-266.)
   * no buffer broadcast: DDP re-broadcasts `queue` (403 MB) from rank 0 on every forward; the
     replicas are identical by construction (same gathered keys, same order), so nothing is sent.
@@ -39,7 +40,7 @@ def average_(flat: torch.Tensor, group=None):
 class DataParallel(nn.Module):
     """`.module` is the wrapped MoCo (same attribute the reference reads from its DDP wrapper)."""
 
-    def __init__(self, module: nn.Module, optimizer=None):
+    def __init__(self, module: nn.Module, optimizer=None, chunk_layers: int = 3):
         super().__init__()
         self.module = module
         self._encoders = [m for m in module.modules() if isinstance(m, FlatBertEncoder)
@@ -47,7 +48,8 @@ class DataParallel(nn.Module):
         self._comm = None
         self._done = None
         for enc in self._encoders:
-            enc._post_backward = [self._reduce]
+            enc._range_hooks = [self._reduce_range]
+            enc.backward_chunk_layers = chunk_layers if world() > 1 else 0
         if optimizer is not None:
             self.attach(optimizer)
 
@@ -57,10 +59,11 @@ class DataParallel(nn.Module):
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
 
-    def _reduce(self, enc):
-        if world() == 1:
+    def _reduce_range(self, enc, lo, hi):
+        """gradient elements [lo, hi) of the flat array are final: average them across ranks on the side stream"""
+        if world() == 1 or hi <= lo:
             return
-        g = enc.flat_grads(create=False)
+        g = enc.flat_grads(create=False)[lo:hi]
         if g.is_cuda:
             if self._comm is None:
                 self._comm = torch.cuda.Stream()

@@ -97,12 +97,17 @@ int czc_encoder_forward(const czc_bert_shape* s, const float* params_f32, const 
                         float* emb_out, czc_stream_t stream);
 
 /* grads_f32 (flat, same layout as params) += d(sum(emb * d_emb))/d(params)  when accumulate != 0,
- * or is overwritten when accumulate == 0.  `workspace` is the one the matching forward filled. */
+ * or is overwritten when accumulate == 0.  `workspace` is the one the matching forward filled.
+ * The backward may be issued in layer ranges [layer_lo, layer_hi), top range first (layer_hi = num_layers runs
+ * the pooling backward, layer_lo = 0 the embedding backward; the inter-range gradient stays in `scratch`), so the
+ * caller can all-reduce each finished range's gradients on another stream while the next range computes.
+ * One call with (num_layers, 0) is the whole backward. */
 int czc_encoder_backward(const czc_bert_shape* s, const float* params_f32, const uint16_t* params_bf16,
                          const int64_t* ids, const uint8_t* mask, int batch, int seq,
                          int pooling, int normalize, int training, uint32_t seed,
                          void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes,
-                         const float* d_emb, float* grads_f32, int accumulate, czc_stream_t stream);
+                         const float* d_emb, float* grads_f32, int accumulate, int layer_hi, int layer_lo,
+                         czc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * MoCo head — replaces MoCo._compute_logits + "/ temperature" + F.cross_entropy + stats
@@ -188,7 +193,6 @@ int czc_gemm_bf16(int a_layout, int b_layout, int epilogue, int M, int N, int K,
 /* Tile configuration used by every later GEMM launch that does not choose one itself:
  * 0 = built-in choice, 1 = 256x256 tile (8 waves, 1 workgroup/CU), 2 = 128x128 (4 waves, 2 workgroups/CU) */
 int czc_gemm_set_tile(int cfg);
-
 /* Timing probe (bench only): records hipEvents on the launch stream around every czc GEMM launch whose
  * (layouts, epilogue, M, N, K) match, up to max_samples launches; max_samples <= 0 disarms.
  * czc_probe_read synchronises on the recorded events and returns their summed duration. */
@@ -205,11 +209,13 @@ int czc_attention_forward(const uint16_t* qkv, const uint8_t* mask, int batch, i
                           float dropout_p, uint32_t seed, uint32_t site,
                           uint16_t* ctx, float* lse, czc_stream_t stream);
 /* dqkv bf16 [batch*seq, 3H];  delta f32 [batch, heads, seq] is scratch;  d_bias_qkv f32 [3H] (may be NULL)
- * += column sums of dqkv = the bias gradient of the fused QKV projection */
+ * += column sums of dqkv = the bias gradient of the fused QKV projection, accumulated through `partials`
+ * (czc_attention_bias_scratch_floats floats of scratch: one row per workgroup, no contended atomics) */
+int64_t czc_attention_bias_scratch_floats(int batch, int seq, int heads);
 int czc_attention_backward(const uint16_t* qkv, const uint8_t* mask, const uint16_t* ctx,
                            const uint16_t* dctx, const float* lse, int batch, int seq, int heads,
                            float dropout_p, uint32_t seed, uint32_t site,
-                           float* delta, uint16_t* dqkv, float* d_bias_qkv, czc_stream_t stream);
+                           float* delta, uint16_t* dqkv, float* d_bias_qkv, float* partials, czc_stream_t stream);
 
 /* x = dropout(LN(word[ids] + pos[s] + type[0]))  bf16 [M,H];  stats f32 [M,2] = (mean, rstd) */
 int czc_embed_ln_forward(const int64_t* ids, int batch, int seq, int hidden, int vocab,
@@ -222,7 +228,7 @@ int czc_embed_ln_backward(const int64_t* ids, int batch, int seq, int hidden, in
                           const float* gamma, const float* stats,
                           float dropout_p, uint32_t seed, uint32_t site, const uint16_t* dx,
                           float* d_word, float* d_pos, float* d_type0, float* d_gamma, float* d_beta,
-                          czc_stream_t stream);
+                          float* partials, czc_stream_t stream);
 
 /* x = LN(dropout(y) + resid) ; y already holds the dense bias */
 int czc_residual_ln_forward(const uint16_t* y, const uint16_t* resid, int rows, int hidden,
@@ -230,12 +236,16 @@ int czc_residual_ln_forward(const uint16_t* y, const uint16_t* resid, int rows, 
                             float dropout_p, uint32_t seed, uint32_t site,
                             uint16_t* x, float* stats, czc_stream_t stream);
 /* dz = dLN(dx [+ dx2]) ;  dz_out = dz (residual branch), dy_out = dropout-masked dz (dense branch);
- * d_gamma/d_beta/d_bias (+)= column sums (atomic fp32).  dy_out may equal dz_out when p == 0. */
+ * d_gamma/d_beta/d_bias (+)= column sums.  dy_out may equal dz_out when p == 0.
+ * partials: czc_colsum_scratch_floats(hidden) floats of scratch for per-workgroup partial sums (NULL = contended
+ * fp32 atomics, several times slower on large inputs). */
+int64_t czc_colsum_scratch_floats(int hidden);
+int czc_reduce_partials(const float* partials, int nrows, int row_stride, int ncols, float* dst, czc_stream_t stream);
 int czc_residual_ln_backward(const uint16_t* dx, const uint16_t* dx2, const uint16_t* y,
                              const uint16_t* resid, const float* stats, int rows, int hidden,
                              const float* gamma, float dropout_p, uint32_t seed, uint32_t site,
                              uint16_t* dz_out, uint16_t* dy_out,
-                             float* d_gamma, float* d_beta, float* d_bias, czc_stream_t stream);
+                             float* d_gamma, float* d_beta, float* d_bias, float* partials, czc_stream_t stream);
 
 /* col[n] += sum_m x[m][n]  (bias gradients) */
 int czc_colsum_bf16(const uint16_t* x, int rows, int cols, int ld, float* col, czc_stream_t stream);

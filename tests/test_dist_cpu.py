@@ -56,6 +56,27 @@ def _worker(rank, world, port, out):
         parallel.average_(flat)
         assert torch.allclose(flat, ref, atol=1e-7)
 
+        # DataParallel's ranged reduction: the flat gradient is averaged range by range (matrix slices of
+        # 3 layers, top first, then the vector + embedding tail) and every element exactly once
+        from src.contriever import Contriever, bert_config
+        enc = Contriever(bert_config(vocab_size=64, hidden_size=64, num_hidden_layers=4, num_attention_heads=1,
+                                     intermediate_size=128, max_position_embeddings=16))
+        dp = parallel.DataParallel(enc, chunk_layers=3)
+        assert enc.backward_chunk_layers == 3
+        n = enc.flat_params.numel()
+        enc._flat_grad = O.det_uniform((n,), 21 + rank)
+        want = sum(O.det_uniform((n,), 21 + r) for r in range(world)) / world
+        la = enc._n_mat // 4
+        seen = torch.zeros(n, dtype=torch.int32)
+        hi = 4
+        while hi > 0:
+            lo = max(0, hi - 3)
+            dp._reduce_range(enc, lo * la, hi * la); seen[lo * la:hi * la] += 1
+            hi = lo
+        dp._reduce_range(enc, enc._n_mat, n); seen[enc._n_mat:] += 1
+        assert int(seen.min()) == 1 and int(seen.max()) == 1
+        assert torch.allclose(enc._flat_grad, want, atol=1e-7)
+
         # stats: weighted mean over ranks lands on rank 0
         st = utils.WeightedAvgStats()
         st.update({"train/loss": (float(rank + 1), 4 * (rank + 1))})

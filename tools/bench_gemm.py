@@ -1,5 +1,6 @@
-"""Dev tool: time the GEMM shapes of one bert-base layer (B*S = 65536 tokens) under both tile configurations."""
-import os, sys
+"""Dev tool: A/B the GEMM shapes of one bert-base layer (65536 tokens) across settings, interleaved in ONE
+process (variants x rounds), reporting the median per variant (cdna guide §5.4 rule 24)."""
+import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from czech_contriever_amd import lib as L, ops
@@ -21,34 +22,30 @@ cases = [
     ("bwd dX1   add       M,768,3072", lambda: ops.gemm(YI, W["w1"], b_layout=1, epilogue="add", aux=YH), 2 * M * 768 * 3072),
     ("bwd dctx  store     M,768,768", lambda: ops.gemm(YH, W["o"], b_layout=1), 2 * M * 768 * 768),
     ("bwd dXin  add       M,768,2304", lambda: ops.gemm(Y3, W["qkv"], b_layout=1, epilogue="add", aux=YH), 2 * M * 768 * 2304),
+    ("dW2 [768,3072] splitk 7", lambda: ops.gemm(YH, Xi, a_layout=1, b_layout=1, epilogue="f32", M=768, N=3072, K=M, splitk=7), 2 * M * 768 * 3072),
+    ("dWqkv [2304,768] splitk 9", lambda: ops.gemm(Y3, X, a_layout=1, b_layout=1, epilogue="f32", M=2304, N=768, K=M, splitk=9), 2 * M * 768 * 2304),
 ]
-def dw(name, dy, x, No, Ko):
-    for sp in (None,):
-        pass
-    return name
-def splits_for(Mo, No, tile):
-    tiles = -(-Mo // tile) * -(-No // tile)
-    return max(1, min(1024, (256 if tile == 256 else 512) // tiles))
-dws = [("dW2 [768,3072]", YH, Xi, 768, 3072), ("dW1 [3072,768]", YI, X, 3072, 768), ("dWo [768,768]", YH, X, 768, 768),
-       ("dWqkv [2304,768]", Y3, X, 2304, 768)]
-def timeit(fn, n=10):
-    fn(); torch.cuda.synchronize()
+variants = [("tile256", 1, 0), ("tile256 again", 1, 0)]
+if len(sys.argv) > 1 and sys.argv[1] == "tiles":
+    variants = [("tile256", 1, 0), ("tile128", 2, 0)]
+def timeit(fn, n=8):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-for cfg, tile in ((1, 256), (2, 128)):
-    L.check(lib.czc_gemm_set_tile(cfg))
-    tot = 0.0
-    for name, fn, fl in cases:
-        ms = timeit(fn); tot += ms
-        print(f"cfg{cfg} {name:36s} {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF/s", flush=True)
-    for name, dy, x, Mo, No in dws:
-        for mult in (1, 2):
-            sp = splits_for(Mo, No, tile) * mult
-            fn = lambda: ops.gemm(dy, x, a_layout=1, b_layout=1, epilogue="f32", M=Mo, N=No, K=M, splitk=sp)
-            ms = timeit(fn)
-            print(f"cfg{cfg} {name:20s} splitk={sp:3d}            {ms*1e3:8.1f} us  {2*M*Mo*No/ms/1e9:7.1f} TF/s", flush=True)
-    print(f"cfg{cfg} sum of 8 activation GEMMs: {tot*1e3:.0f} us", flush=True)
+tot = {v[0]: 0.0 for v in variants}
+for name, fn, fl in cases:
+    res = {v[0]: [] for v in variants}
+    for rnd in range(6):
+        for vn, cfg, stag in variants:
+            L.check(lib.czc_gemm_set_tile(cfg))
+            t = timeit(fn)
+            if rnd: res[vn].append(t)
+    line = f"{name:32s}"
+    for vn, _, _ in variants:
+        med = statistics.median(res[vn]); tot[vn] += med
+        line += f" | {vn}: {med*1e3:7.1f} us {fl/med/1e9:7.1f} TF/s"
+    print(line, flush=True)
+print("sums:", {k: round(v * 1e3) for k, v in tot.items()})
 L.check(lib.czc_gemm_set_tile(0))
