@@ -31,6 +31,11 @@ def average_(flat: torch.Tensor, group=None):
         return flat
     if dist.get_backend(group) == "nccl":
         dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
+    elif flat.is_cuda:
+        # gloo rehearsal of the multi-GPU path on a one-GPU box: stage through the host
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host.div_(dist.get_world_size(group)))
     else:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         flat.div_(dist.get_world_size(group))

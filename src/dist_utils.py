@@ -72,6 +72,12 @@ def gather_nograd(x: torch.Tensor, process_group=None, out: torch.Tensor = None)
     w = dist.get_world_size(process_group)
     if out is None:
         out = torch.empty((w * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    if x.is_cuda and dist.get_backend(process_group) != "nccl":
+        # gloo rehearsal on a one-GPU box: gather on the host
+        host = torch.empty(out.shape, dtype=x.dtype)
+        dist.all_gather_into_tensor(host, x.detach().cpu().contiguous(), group=process_group)
+        out.copy_(host)
+        return out
     dist.all_gather_into_tensor(out, x.contiguous(), group=process_group)
     return out
 
