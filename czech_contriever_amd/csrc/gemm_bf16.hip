@@ -30,9 +30,12 @@ constexpr int BK = 64;
 //   big   = 2x4 waves, TM 8: 256x256 tile, 512 threads, 128 KiB LDS, one workgroup per CU
 //   small = 2x2 waves, TM 4: 128x128 tile, 256 threads,  64 KiB LDS, two workgroups per CU (a workgroup's
 //           epilogue stores and tile prologue overlap the other's MFMA work)
-template <int WM_, int WN_, int TM_>
+//   (measured and dropped: 2x2 waves with TM 8, TN 8 -- one wave per SIMD owning 128x128 outputs in 256
+//    accumulator registers -- ran 0.65-0.75x the speed of `big` under compiler scheduling; `small` is 3-7 % slower
+//    than `big` on these shapes and is kept for small problems)
+template <int WM_, int WN_, int TM_, int TN_ = 4>
 struct Cfg {
-  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = 4;
+  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
   static constexpr int NW = WM * WN, NT = NW * 64;
   static constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   static constexpr int TILE_A = BM * BK * 2, TILE_B = BN * BK * 2;
@@ -116,7 +119,8 @@ __device__ __forceinline__ void swizzle_tile(int bid, int nwg, int tiles_n, int&
 template <int AL, int BL, int EPI, class CF>
 __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int BM = CF::BM, BN = CF::BN, TM = CF::TM, WN = CF::WN;
+  constexpr int BM = CF::BM, BN = CF::BN, TM = CF::TM, TN = CF::TN, WN = CF::WN;
+  constexpr int WNC = TN * 16;  // columns per wave
   constexpr int TILE_BYTES_A = CF::TILE_A, BUF_BYTES = CF::BUF;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -133,11 +137,11 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   if (kt_end > kt_total) kt_end = kt_total;
   const int nt = kt_end - kt_begin;
 
-  f32x4 acc[TM][4];
+  f32x4 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   auto stage = [&](int t, int buf) {
     unsigned char* ta = smem + buf * BUF_BYTES;
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   //   global_load_lds of tile t+2 into tile t's buffer (lands during the next K-tile)
   //   phase 3: MFMA(t, ks1, rows hi)   || read A(t+1, ks0, lo), B(t+1, ks0)
   constexpr int HM = TM / 2;
-  bf16x8 fa0[HM], fa1[HM], fb0[4], fb1[4];
+  bf16x8 fa0[HM], fa1[HM], fb0[TN], fb1[TN];
   auto read_a = [&](bf16x8 (&fa)[HM], int buf, int ks, int half) {
     const unsigned char* ta = smem + buf * BUF_BYTES;
 #pragma unroll
@@ -166,15 +170,15 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
       fa[i] = (AL == 0) ? frag_kmajor(ta, wm * TM * 16, half * HM + i, ks, lane)
                         : frag_mnmajor(ta, wm * TM * 16, half * HM + i, ks, lane);
   };
-  auto read_b = [&](bf16x8 (&fb)[4], int buf, int ks) {
+  auto read_b = [&](bf16x8 (&fb)[TN], int buf, int ks) {
     const unsigned char* tb = smem + buf * BUF_BYTES + TILE_BYTES_A;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      fb[j] = (BL == 0) ? frag_kmajor(tb, wn * 64, j, ks, lane) : frag_mnmajor(tb, wn * 64, j, ks, lane);
+    for (int j = 0; j < TN; ++j)
+      fb[j] = (BL == 0) ? frag_kmajor(tb, wn * WNC, j, ks, lane) : frag_mnmajor(tb, wn * WNC, j, ks, lane);
   };
 #define CZC_MFMA_HALF(FA, FB, HALF)                                                                  \
   _Pragma("unroll") for (int i = 0; i < HM; ++i)                                                     \
-  _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
+  _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                     \
     acc[(HALF) * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j], FA[i], acc[(HALF) * HM + i][j], 0, 0, 0)
 
   if (nt > 0) {
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                      \
     __builtin_amdgcn_sched_group_barrier(0x008, (NMFMA) / (NREADS), 0);                     \
   }
-  constexpr int NM = HM * 4;  // MFMAs per phase
+  constexpr int NM = HM * TN;  // MFMAs per phase
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     read_a(fa1, buf, 0, 1);
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
     read_a(fa0, buf, 1, 0);
     read_b(fb1, buf, 1);
     CZC_MFMA_HALF(fa1, fb0, 1);
-    CZC_INTERLEAVE(HM * RA + 4 * RB, NM)
+    CZC_INTERLEAVE(HM * RA + TN * RB, NM)
     read_a(fa1, buf, 1, 1);
     CZC_MFMA_HALF(fa0, fb1, 0);
     CZC_INTERLEAVE(HM * RA, NM)
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
     read_a(fa0, buf ^ 1, 0, 0);
     read_b(fb0, buf ^ 1, 0);
     CZC_MFMA_HALF(fa1, fb1, 1);
-    CZC_INTERLEAVE(HM * RA + 4 * RB, NM)
+    CZC_INTERLEAVE(HM * RA + TN * RB, NM)
   }
 #undef CZC_INTERLEAVE
 #undef CZC_MFMA_HALF
@@ -228,8 +232,8 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
     for (int i = 0; i < TM; ++i) {
       const int m = row0 + wm * TM * 16 + 16 * i + mrow;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = col0 + wn * 64 + 16 * j + 4 * nq;
+      for (int j = 0; j < TN; ++j) {
+        const int n = col0 + wn * WNC + 16 * j + 4 * nq;
         if (m < a.M && n < a.N) *(f32x4*)(C + (size_t)m * a.ldc + n) = acc[i][j];
       }
     }
@@ -244,8 +248,8 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
     for (int i = 0; i < TM; ++i) {
       float mx = -1e30f, sm = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = col0 + wn * 64 + 16 * j + 4 * nq;
+      for (int j = 0; j < TN; ++j) {
+        const int n = col0 + wn * WNC + 16 * j + 4 * nq;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float z = (n + r < a.N) ? acc[i][j][r] * a.alpha : -1e30f;
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       float se = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) se += __expf(acc[i][j][r] - mx);
       se += __shfl_xor(se, 16, 64); se += __shfl_xor(se, 32, 64);
@@ -295,7 +299,8 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   // bf16 outputs: registers -> LDS (per-wave 128 x 64 bf16 region, 16-B chunks XOR-swizzled by
   // row&7) -> 16-B row segments -> global
   __syncthreads();  // all waves are done reading the operand tiles
-  unsigned char* reg = smem + wave * (TM * 16 * 128);
+  constexpr int ROWB = TN * 32, NCH = TN * 2;   // bytes / 16-B chunks per staged row
+  unsigned char* reg = smem + wave * (TM * 16 * ROWB);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int rl = 16 * i + mrow;
@@ -305,10 +310,10 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
       rv = (m < a.M) ? a.rowv[m] : 0.f;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < TN; ++j) {
       f32x4 v = acc[i][j];
       if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
-        const int n = col0 + wn * 64 + 16 * j + 4 * nq;
+        const int n = col0 + wn * WNC + 16 * j + 4 * nq;
         if (n < a.N) {
           const f32x4 b = *(const f32x4*)(a.bias + n);
           v += b;
@@ -322,20 +327,20 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
       w.x = pack2bf(v[0], v[1]);
       w.y = pack2bf(v[2], v[3]);
       const int chunk = (2 * j + (nq >> 1)) ^ (rl & 7);
-      *(uint2*)(reg + rl * 128 + chunk * 16 + (nq & 1) * 8) = w;
+      *(uint2*)(reg + rl * ROWB + chunk * 16 + (nq & 1) * 8) = w;
     }
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes are done (region is wave-private)
   bf16_t* C = (bf16_t*)a.C;
   float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // DGELU: this lane's 8 columns over its 2*TM rows
 #pragma unroll 4
-  for (int it = 0; it < 2 * TM; ++it) {
+  for (int it = 0; it < TM * 16 * NCH / 64; ++it) {
     const int idx = it * 64 + lane;
-    const int rl = idx >> 3, ch = idx & 7;
+    const int rl = idx / NCH, ch = idx % NCH;
     const int m = row0 + wm * TM * 16 + rl;
-    const int n = col0 + wn * 64 + ch * 8;
+    const int n = col0 + wn * WNC + ch * 8;
     if (m < a.M && n < a.N) {
-      uint4 v = *(const uint4*)(reg + rl * 128 + ((ch ^ (rl & 7)) << 4));
+      uint4 v = *(const uint4*)(reg + rl * ROWB + ((ch ^ (rl & 7)) << 4));
       const size_t off = (size_t)m * a.ldc + n;
       if (EPI == EPI_BIAS_GELU) {
         *(uint4*)(C + off) = v;
@@ -375,12 +380,13 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float t = csum[j];
-      t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+#pragma unroll
+      for (int o = NCH; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
       csum[j] = t;
     }
     // one partial row per (M-tile, wave row): colsum[(tm * WM + wm)][N], written whole (no atomics)
-    const int n = col0 + wn * 64 + (lane & 7) * 8;
-    if ((lane >> 3) == 0 && n < a.N) {
+    const int n = col0 + wn * WNC + (lane % NCH) * 8;
+    if ((lane / NCH) == 0 && n < a.N) {
       float* row = a.colsum + (size_t)(tm * CF::WM + wm) * a.N + n;
       *(f32x4*)row = (f32x4){csum[0], csum[1], csum[2], csum[3]};
       *(f32x4*)(row + 4) = (f32x4){csum[4], csum[5], csum[6], csum[7]};
@@ -413,7 +419,7 @@ template <int AL, int BL, int EPI>
 static int launch(const GemmArgs& a, int splits, hipStream_t st) {
   int cfg = a.cfg ? a.cfg : g_tile_override;
   if (EPI == EPI_LSE || EPI == EPI_SOFTGRAD || a.colsum) cfg = 1;  // partial-sum rows are laid out for 256-row tiles
-  if (cfg == 0) cfg = 1;
+  if (cfg == 0) cfg = (ceil_div(a.M, 256) * ceil_div(a.N, 256) * splits < 128 && !a.colsum) ? 2 : 1;
   if (cfg == 2) return launch_cfg<AL, BL, EPI, CfgSmall>(a, splits, st);
   return launch_cfg<AL, BL, EPI, CfgBig>(a, splits, st);
 }
@@ -512,7 +518,7 @@ extern "C" int czc_gemm_bf16(int a_layout, int b_layout, int epilogue, int M, in
 }
 
 extern "C" int czc_gemm_set_tile(int cfg) {
-  CZC_REQUIRE(cfg >= 0 && cfg <= 2, "czc_gemm_set_tile: cfg=%d (0 heuristic, 1 = 256x256, 2 = 128x128)", cfg);
+  CZC_REQUIRE(cfg >= 0 && cfg <= 2, "czc_gemm_set_tile: cfg=%d (0 default, 1 = 256x256, 2 = 128x128)", cfg);
   g_tile_override = cfg;
   return CZC_OK;
 }

@@ -25,7 +25,7 @@ cases = [
     ("dW2 [768,3072] splitk 7", lambda: ops.gemm(YH, Xi, a_layout=1, b_layout=1, epilogue="f32", M=768, N=3072, K=M, splitk=7), 2 * M * 768 * 3072),
     ("dWqkv [2304,768] splitk 9", lambda: ops.gemm(Y3, X, a_layout=1, b_layout=1, epilogue="f32", M=2304, N=768, K=M, splitk=9), 2 * M * 768 * 2304),
 ]
-variants = [("tile256", 1, 0), ("tile256 again", 1, 0)]
+variants = [("tile256", 1, 0), ("tile128", 2, 0)]
 if len(sys.argv) > 1 and sys.argv[1] == "tiles":
     variants = [("tile256", 1, 0), ("tile128", 2, 0)]
 def timeit(fn, n=8):
