@@ -298,8 +298,10 @@ def adamw_step(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay):
 # --------------------------------------------------------------------------------------
 class MoCoState:
     def __init__(self, cfg: BertShape, Pq, queue, momentum, temperature, label_smoothing=0.0,
-                 norm_query=False, norm_doc=False, pooling="average"):
+                 norm_query=False, norm_doc=False, pooling="average", l2_from_init=0.0):
         self.cfg = cfg
+        self.l2_from_init = l2_from_init                 # src/moco.py:332-336 (weight_decay_from_init)
+        self.P0 = {n: t.clone() for n, t in Pq.items()}
         self.Pq = {n: t.clone().requires_grad_(True) for n, t in Pq.items()}
         self.Pk = {n: t.clone() for n, t in Pq.items()}
         self.queue = queue.clone()
@@ -317,6 +319,9 @@ class MoCoState:
             self.Pk = ema_update(self.Pk, {n: t.detach() for n, t in self.Pq.items()}, self.momentum)
             k = encoder_forward(self.Pk, k_tokens, k_mask, cfg, self.pooling, self.norm_doc, training)
         loss, logits = infonce_loss(q, k, self.queue.clone(), self.temperature, self.label_smoothing)
+        if self.l2_from_init:
+            for n, p in self.Pq.items():
+                loss = loss + self.l2_from_init * ((p - self.P0[n]) ** 2).sum()
         with torch.no_grad():
             self.queue, self.ptr = enqueue(self.queue, self.ptr, k)
         loss.backward()

@@ -1,0 +1,98 @@
+"""The command-line path on the GPU: train.py (config-1-sized plumbing run on synthetic ids), checkpoints,
+auto-resume, and the weight_decay_from_init penalty against the oracle."""
+import json
+import os
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import moco_bert_oracle as O
+from oracle.make_golden import TINY, ragged_batch
+
+
+def _cfg_dir(tmp_path, **extra):
+    d = str(tmp_path / "model")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump(dict(TINY, **extra), f)
+    return d
+
+
+def test_train_cli_runs_saves_and_resumes(tmp_path, monkeypatch):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import train
+    mdir = _cfg_dir(tmp_path)
+    out = str(tmp_path / "run")
+    args = ["--retriever_model_id", mdir, "--random_init", "--output_dir", out, "--save_dir", out,
+            "--chunk_length", "32", "--per_gpu_batch_size", "8", "--target_batch_size", "16", "--queue_size", "64",
+            "--projection_size", "128", "--temperature", "0.05", "--momentum", "0.99", "--lr", "1e-3",
+            "--warmup_steps", "2", "--total_steps", "4", "--save_freq", "2", "--log_freq", "1", "--norm_query", "--norm_doc"]
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    train.main(args)
+    ck = os.path.join(out, "checkpoint")
+    assert os.path.islink(os.path.join(ck, "latest"))
+    assert os.path.exists(os.path.join(ck, "step-2", "checkpoint.pth")) and os.path.exists(os.path.join(ck, "step-4", "checkpoint.pth"))
+    assert os.path.exists(os.path.join(out, "opt.txt"))
+    c4 = torch.load(os.path.join(ck, "step-4", "checkpoint.pth"), map_location="cpu", weights_only=False)
+    assert c4["step"] == 4 and c4["opt"].queue_size == 64
+    # update_freq = 16 / 8 = 2 micro-steps per optimizer step: 4 steps enqueued 8 micro-batches of 8 keys
+    assert int(c4["model"]["queue_ptr"]) == (8 * 8) % 64
+    assert c4["optimizer"]["state"][0]["step"] == 4
+    # auto-resume: the output directory exists -> continues from `latest` up to the new total_steps
+    args2 = [a if a != "4" else "6" for a in args]
+    train.main(args2)
+    c6 = torch.load(os.path.join(ck, "step-6", "checkpoint.pth"), map_location="cpu", weights_only=False)
+    assert c6["step"] == 6
+    # like the reference, a resumed run keeps the CHECKPOINT's schedule (utils.load builds the optimizer from
+    # opt_checkpoint, src/utils.py:86-88): total_steps was 4 there, so lambda(4..5) = 0 and the weights stand still,
+    # while the Adam moments, the EMA and the queue keep moving
+    w4 = c4["model"]["encoder_q.encoder.layer.0.output.dense.weight"]
+    w6 = c6["model"]["encoder_q.encoder.layer.0.output.dense.weight"]
+    assert torch.equal(w4, w6)
+    assert not torch.equal(c4["optimizer"]["state"][5]["exp_avg"], c6["optimizer"]["state"][5]["exp_avg"])
+    assert not torch.equal(c4["model"]["queue"], c6["model"]["queue"])
+    # the reference's loader strips `encoder_q.` and loads a plain Contriever (src/contriever.py:126-144)
+    from src.contriever import load_retriever
+    enc, tok, mid = load_retriever(os.path.join(ck, "step-6"))
+    assert torch.equal(enc.state_dict()["encoder.layer.0.output.dense.weight"], w6)
+
+
+def test_weight_decay_from_init_matches_oracle(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from src import moco, utils
+    dev = torch.device("cuda:0")
+    mdir = _cfg_dir(tmp_path, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    wd = 0.5   # large on purpose: the penalty must move the loss visibly after one step
+    opt = types.SimpleNamespace(
+        queue_size=64, momentum=0.99, temperature=0.05, label_smoothing=0.0, norm_doc=True, norm_query=True,
+        moco_train_mode_encoder_k=False, weight_decay=wd, weight_decay_from_init=True, retriever_model_id=mdir,
+        pooling="average", random_init=True, projection_size=128, optim="adamw", lr=1e-2, beta1=0.9, beta2=0.98,
+        eps=1e-6, warmup_steps=0, total_steps=10, lr_min_ratio=1.0, scheduler="linear")
+    model = moco.MoCo(opt)
+    cfg_o = O.BertShape(**TINY)
+    P = O.make_params(cfg_o, 71)
+    model.encoder_q.load_state_dict(P); model.encoder_k.load_state_dict(P)
+    model.init_weights = {k: v.clone() for k, v in model.encoder_q.state_dict().items()}
+    queue = torch.nn.functional.normalize(O.det_uniform((128, 64), 72), dim=0)
+    with torch.no_grad():
+        model.queue.copy_(queue)
+    model = model.to(dev).train()
+    optimizer, scheduler = utils.set_optim(opt, model)   # weight_decay_from_init -> AdamW without decay (reference :139-142)
+    assert optimizer.param_groups[0]["weight_decay"] == 0.0
+    st = O.MoCoState(cfg_o, P, queue, momentum=0.99, temperature=0.05, norm_query=True, norm_doc=True, l2_from_init=wd)
+    for step in range(3):
+        qt, qm = ragged_batch(8, 24, 7300 + step, 512, [24, 17, 3, 24, 9, 24, 12, 20])
+        kt, km = ragged_batch(8, 24, 7400 + step, 512, [20, 24, 5, 11, 24, 7, 24, 16])
+        loss, _ = model(qt.to(dev), qm.to(dev), kt.to(dev), km.to(dev))
+        loss.backward()
+        optimizer.step(); scheduler.step(); model.zero_grad()
+        ref, _, _, _ = st.forward_backward(qt, qm, kt, km)
+        st.optimizer_step(1e-2, weight_decay=0.0)
+        assert abs(float(loss.detach()) - float(ref)) < 2e-2 * max(1.0, abs(float(ref))), (step, float(loss.detach()), float(ref))
+    assert float(loss.detach()) > 1.0   # the penalty term is active (InfoNCE alone is < 1 here at step 2)
