@@ -207,7 +207,10 @@ extern "C" int czc_encoder_forward(const czc_bert_shape* s, const float* params_
     RC(gemm(0, 0, EPI_BIAS, M, H, H, BUF(w.ctx), H, WB(CZC_P_WO, l), H, BUF(w.y1), H, PF(CZC_P_BO, l), nullptr, nullptr, 1, st));
     RC(czc_residual_ln_forward(BUF(w.y1), BUF(e.x[l]), M, H, PF(CZC_P_LN1W, l), PF(CZC_P_LN1B, l), s->layer_norm_eps, ph,
                                seed, SITE_H1(l), BUF(w.x1), FBUF(w.st1), stream));
-    RC(gemm(0, 0, EPI_BIAS_GELU, M, I, H, BUF(w.x1), H, WB(CZC_P_W1, l), H, BUF(w.u), I, PF(CZC_P_B1, l), nullptr, BUF(w.hact), 1, st));
+    if (save_for_backward)
+      RC(gemm(0, 0, EPI_BIAS_GELU, M, I, H, BUF(w.x1), H, WB(CZC_P_W1, l), H, BUF(w.u), I, PF(CZC_P_B1, l), nullptr, BUF(w.hact), 1, st));
+    else   // nothing differentiates through this pass (key encoder, inference): keep gelu(u) only
+      RC(gemm(0, 0, EPI_BIAS_GELU1, M, I, H, BUF(w.x1), H, WB(CZC_P_W1, l), H, BUF(w.hact), I, PF(CZC_P_B1, l), nullptr, nullptr, 1, st));
     RC(gemm(0, 0, EPI_BIAS, M, H, I, BUF(w.hact), I, WB(CZC_P_W2, l), I, BUF(w.y2), H, PF(CZC_P_B2, l), nullptr, nullptr, 1, st));
     RC(czc_residual_ln_forward(BUF(w.y2), BUF(w.x1), M, H, PF(CZC_P_LN2W, l), PF(CZC_P_LN2B, l), s->layer_norm_eps, ph,
                                seed, SITE_H2(l), BUF(e.x[l + 1]), FBUF(w.st2), stream));

@@ -28,6 +28,7 @@ struct GemmArgs {
 #define EPI_F32 5
 #define EPI_LSE 6       // head forward: per-row (max, sumexp, sum) partials of alpha*acc
 #define EPI_SOFTGRAD 7  // head backward: C = exp(alpha*acc - rowv[m]) - beta   (bf16)
+#define EPI_BIAS_GELU1 8 // C = gelu(acc + bias) only (inference / key encoder: the pre-activation is not kept)
 
 
 // checks shapes, picks the instantiation and launches; returns a CZC_* code

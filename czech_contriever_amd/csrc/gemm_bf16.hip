@@ -312,7 +312,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       f32x4 v = acc[i][j];
-      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU1) {
         const int n = col0 + wn * WNC + 16 * j + 4 * nq;
         if (n < a.N) {
           const f32x4 b = *(const f32x4*)(a.bias + n);
@@ -350,6 +350,13 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
         g.z = pack2bf(gelu_f(bflo(v.z)), gelu_f(bfhi(v.z)));
         g.w = pack2bf(gelu_f(bflo(v.w)), gelu_f(bfhi(v.w)));
         *(uint4*)((bf16_t*)a.C2 + off) = g;
+      } else if (EPI == EPI_BIAS_GELU1) {
+        uint4 g;
+        g.x = pack2bf(gelu_f(bflo(v.x)), gelu_f(bfhi(v.x)));
+        g.y = pack2bf(gelu_f(bflo(v.y)), gelu_f(bfhi(v.y)));
+        g.z = pack2bf(gelu_f(bflo(v.z)), gelu_f(bfhi(v.z)));
+        g.w = pack2bf(gelu_f(bflo(v.w)), gelu_f(bfhi(v.w)));
+        *(uint4*)(C + off) = g;
       } else if (EPI == EPI_DGELU) {
         const uint4 u = *(const uint4*)(a.aux + off);
         float e[8];
@@ -477,6 +484,9 @@ static int gemm_dispatch_inner(int al, int bl, int epi, GemmArgs a, int splitk, 
     case EPI_BIAS_GELU:
       CZC_REQUIRE(a.bias && a.C2, "czc_gemm: bias+gelu epilogue needs bias and C2");
       return launch_layout<EPI_BIAS_GELU>(al, bl, a, splitk, st);
+    case EPI_BIAS_GELU1:
+      CZC_REQUIRE(a.bias && al == 0 && bl == 0, "czc_gemm: bias+gelu(only) epilogue needs bias and K-major operands");
+      return launch<0, 0, EPI_BIAS_GELU1>(a, 1, st);
     case EPI_DGELU: CZC_REQUIRE(a.aux, "czc_gemm: dgelu epilogue needs aux"); return launch_layout<EPI_DGELU>(al, bl, a, splitk, st);
     case EPI_ADD: CZC_REQUIRE(a.aux, "czc_gemm: add epilogue needs aux"); return launch_layout<EPI_ADD>(al, bl, a, splitk, st);
     case EPI_F32: return launch_layout<EPI_F32>(al, bl, a, splitk, st);
