@@ -81,9 +81,14 @@ __device__ __forceinline__ bf16x8 ld_frag_global(const bf16_t* p) {
   const uint4 v = *(const uint4*)p;
   return __builtin_bit_cast(bf16x8, v);
 }
-__device__ __forceinline__ float keep16(uint32_t r, int odd, uint32_t thr, float inv_keep) {
-  const uint32_t d = odd ? (r >> 16) : (r & 0xffffu);
-  return d >= thr ? inv_keep : 0.f;
+// dropout element index of the probability (b, head, q, key): ((b*heads + head)*S + q) * S4 + key with
+// S4 = S rounded up to 4, so that 4 consecutive keys starting at a multiple of 4 are exactly one RNG quad
+__device__ __forceinline__ void keep4(uint32_t key, uint32_t e, uint32_t thr, float inv_keep, float (&z)[4]) {
+  const czc_quad q = czc_rng_quad(key, e >> 2);
+  z[0] = ((q.lo & 0xffffu) >= thr) ? inv_keep : 0.f;
+  z[1] = ((q.lo >> 16) >= thr) ? inv_keep : 0.f;
+  z[2] = ((q.hi & 0xffffu) >= thr) ? inv_keep : 0.f;
+  z[3] = ((q.hi >> 16) >= thr) ? inv_keep : 0.f;
 }
 
 struct AttnArgs {
@@ -129,7 +134,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
   f32x16 o[2];
   o[0] = o[1] = (f32x16)(0.f);
   float m = -1.0e30f, l = 0.f;
-  const uint32_t erow = DROP ? ((uint32_t)((b * a.nh + hh) * S + (q0 + r)) * (uint32_t)S) : 0u;
+  const uint32_t S4 = (uint32_t)((S + 3) & ~3);
+  const uint32_t rkey = czc_rng_key(a.seed, a.site);
+  const uint32_t erow = DROP ? ((uint32_t)((b * a.nh + hh) * S + (q0 + r)) * S4) : 0u;
 
   TileRegs<64> kr, vr;
   tile_fetch<64>(kr, base + a.H, H3, S, tid);
@@ -173,17 +180,17 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
           ps += p;
         }
         l = l * alpha + ps;
-        o[0] *= alpha;
-        o[1] *= alpha;
+        if (__any(alpha != 1.0f)) {   // exact: when no row's running max moved, alpha == 1 in every lane
+          o[0] *= alpha;
+          o[1] *= alpha;
+        }
         if (DROP) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const uint32_t e = erow + (uint32_t)(kb0 + 32 * tt + 8 * g + 4 * h);
-            const uint32_t r0 = czc_rng_pair(a.seed, a.site, e >> 1), r1 = czc_rng_pair(a.seed, a.site, (e >> 1) + 1);
-            s[4 * g + 0] *= keep16(r0, 0, a.thr, a.inv_keep);
-            s[4 * g + 1] *= keep16(r0, 1, a.thr, a.inv_keep);
-            s[4 * g + 2] *= keep16(r1, 0, a.thr, a.inv_keep);
-            s[4 * g + 3] *= keep16(r1, 1, a.thr, a.inv_keep);
+            float z[4];
+            keep4(rkey, erow + (uint32_t)(kb0 + 32 * tt + 8 * g + 4 * h), a.thr, a.inv_keep, z);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[4 * g + j] *= z[j];
           }
         }
 #pragma unroll
@@ -261,7 +268,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
 
   f32x16 dq[2];
   dq[0] = dq[1] = (f32x16)(0.f);
-  const uint32_t erow = DROP ? ((uint32_t)((b * a.nh + hh) * S + (q0 + r)) * (uint32_t)S) : 0u;
+  const uint32_t S4 = (uint32_t)((S + 3) & ~3);
+  const uint32_t rkey = czc_rng_key(a.seed, a.site);
+  const uint32_t erow = DROP ? ((uint32_t)((b * a.nh + hh) * S + (q0 + r)) * S4) : 0u;
 
   TileRegs<64> kr, vr;
   tile_fetch<64>(kr, base + a.H, H3, S, tid);
@@ -290,10 +299,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
         const f32x4 bias = *(const f32x4*)(mb + kb0 + 32 * tt + 8 * g + 4 * h);
         float z[4] = {1.f, 1.f, 1.f, 1.f};
         if (DROP) {
-          const uint32_t e = erow + (uint32_t)(kb0 + 32 * tt + 8 * g + 4 * h);
-          const uint32_t r0 = czc_rng_pair(a.seed, a.site, e >> 1), r1 = czc_rng_pair(a.seed, a.site, (e >> 1) + 1);
-          z[0] = keep16(r0, 0, a.thr, a.inv_keep); z[1] = keep16(r0, 1, a.thr, a.inv_keep);
-          z[2] = keep16(r1, 0, a.thr, a.inv_keep); z[3] = keep16(r1, 1, a.thr, a.inv_keep);
+          keep4(rkey, erow + (uint32_t)(kb0 + 32 * tt + 8 * g + 4 * h), a.thr, a.inv_keep, z);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -380,7 +386,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
   }
   f32x16 dk[2], dv[2];
   dk[0] = dk[1] = dv[0] = dv[1] = (f32x16)(0.f);
-  const uint32_t ebase = (uint32_t)((b * a.nh + hh) * S) * (uint32_t)S + (uint32_t)(k0 + r);
+  const uint32_t S4 = (uint32_t)((S + 3) & ~3);
+  const uint32_t rkey = czc_rng_key(a.seed, a.site);
+  const uint32_t ebase = (uint32_t)((b * a.nh + hh) * S) * S4 + (uint32_t)(k0 + r);
 
   TileRegs<64> qr, dr;
   float lreg = 0.f, dreg = 0.f;
@@ -425,8 +433,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
               const float p = __builtin_amdgcn_exp2f(s[4 * g + j] * c2 + kbias - l4[j]);
               float z = 1.f;
               if (DROP) {
-                const uint32_t e = ebase + (uint32_t)(qb0 + 32 * hf + 8 * g + 4 * h + j) * (uint32_t)S;
-                z = keep16(czc_rng_pair(a.seed, a.site, e >> 1), (int)(e & 1u), a.thr, a.inv_keep);
+                const uint32_t e = ebase + (uint32_t)(qb0 + 32 * hf + 8 * g + 4 * h + j) * S4;
+                z = czc_draw16(czc_rng_quad(rkey, e >> 2), e & 3u) >= a.thr ? a.inv_keep : 0.f;
               }
               const float dpz = z * dp[4 * g + j];
               dp[4 * g + j] = p * (dpz - d4[j]);  // dS

@@ -62,23 +62,35 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- counter-based dropout RNG -------------------------------------------------------
-// One 32-bit hash gives two 16-bit uniform draws.  keep <=> draw >= thr, thr = round(p*65536).
-// The same function is restated in numpy by tests/dropout_ref.py so that the oracle can be
-// given identical masks.
+// Elements 4i .. 4i+3 of a dropout site share ONE mixed word finished twice (64 bits): 16 bits per element,
+// keep <=> draw >= thr, thr = round(p * 65536).  Nothing is stored: the backward regenerates the same bits.
+// tests/dropout_ref.py restates this in numpy so that the oracle can be handed identical masks.
 __host__ __device__ __forceinline__ uint32_t czc_hash32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352du;
   x ^= x >> 15; x *= 0x846ca68bu;
   x ^= x >> 16;
   return x;
 }
-__host__ __device__ __forceinline__ uint32_t czc_rng_pair(uint32_t seed, uint32_t site, uint32_t pair_index) {
-  return czc_hash32(pair_index ^ czc_hash32(seed + 0x9E3779B9u * (site + 1u)));
+__host__ __device__ __forceinline__ uint32_t czc_rng_key(uint32_t seed, uint32_t site) {
+  return czc_hash32(seed + 0x9E3779B9u * (site + 1u));
 }
-// keep-flag of element e (pairs are (2i, 2i+1))
+struct czc_quad { uint32_t lo, hi; };   // draws: lo & 0xffff, lo >> 16, hi & 0xffff, hi >> 16
+__host__ __device__ __forceinline__ czc_quad czc_rng_quad(uint32_t key, uint32_t quad_index) {
+  uint32_t x = quad_index ^ key;
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15;
+  czc_quad q;                           // two finalisers of the same mixed word, different odd multipliers
+  q.lo = x * 0x846ca68bu; q.lo ^= q.lo >> 16;
+  q.hi = x * 0xc2b2ae35u; q.hi ^= q.hi >> 16;
+  return q;
+}
+__host__ __device__ __forceinline__ uint32_t czc_draw16(czc_quad q, uint32_t sel) {
+  const uint32_t w = (sel & 2u) ? q.hi : q.lo;
+  return (sel & 1u) ? (w >> 16) : (w & 0xffffu);
+}
+// keep-flag of element e
 __host__ __device__ __forceinline__ bool czc_keep(uint32_t seed, uint32_t site, uint32_t e, uint32_t thr) {
-  uint32_t r = czc_rng_pair(seed, site, e >> 1);
-  uint32_t d = (e & 1u) ? (r >> 16) : (r & 0xffffu);
-  return d >= thr;
+  return czc_draw16(czc_rng_quad(czc_rng_key(seed, site), e >> 2), e & 3u) >= thr;
 }
 __host__ __device__ __forceinline__ uint32_t czc_drop_thr(float p) {
   return (uint32_t)(p * 65536.0f + 0.5f);

@@ -21,15 +21,14 @@ __device__ __forceinline__ void st_bf4(bf16_t* p, f32x4 v) {
   w.y = pack2bf(v[2], v[3]);
   *(uint2*)p = w;
 }
-// keep-scale for 4 consecutive elements starting at even element index e (2 RNG pairs)
+// keep-scale for the 4 consecutive elements e .. e+3 (e a multiple of 4: one RNG quad)
 __device__ __forceinline__ f32x4 drop_scale4(uint32_t seed, uint32_t site, uint32_t e, uint32_t thr, float inv_keep) {
-  const uint32_t r0 = czc_rng_pair(seed, site, e >> 1);
-  const uint32_t r1 = czc_rng_pair(seed, site, (e >> 1) + 1);
+  const czc_quad q = czc_rng_quad(czc_rng_key(seed, site), e >> 2);
   f32x4 s;
-  s[0] = ((r0 & 0xffffu) >= thr) ? inv_keep : 0.f;
-  s[1] = ((r0 >> 16) >= thr) ? inv_keep : 0.f;
-  s[2] = ((r1 & 0xffffu) >= thr) ? inv_keep : 0.f;
-  s[3] = ((r1 >> 16) >= thr) ? inv_keep : 0.f;
+  s[0] = ((q.lo & 0xffffu) >= thr) ? inv_keep : 0.f;
+  s[1] = ((q.lo >> 16) >= thr) ? inv_keep : 0.f;
+  s[2] = ((q.hi & 0xffffu) >= thr) ? inv_keep : 0.f;
+  s[3] = ((q.hi >> 16) >= thr) ? inv_keep : 0.f;
   return s;
 }
 
@@ -483,7 +482,10 @@ extern "C" int czc_residual_ln_backward(const uint16_t* dx, const uint16_t* dx2,
   CZC_REQUIRE(dz_out && dy_out, "czc_residual_ln_backward: outputs missing");
   CZC_REQUIRE(!(dropout_p > 0.f && dz_out == dy_out), "czc_residual_ln_backward: dy_out must differ from dz_out when p > 0");
   DROP_ARGS(dropout_p);
+  // 119 VGPRs -> 4 workgroups per CU are resident: exactly one round of 1024 (measured: 2048 -> 206 us, 1024 -> 155 us,
+  // 512 -> 200 us at 65536 x 768)
   int g = row_grid(rows);
+  if (g > 1024) g = 1024;
   LAUNCH_NIT(residual_ln_bwd_kernel, hidden, dim3(g), (hipStream_t)stream, dx, dx2, y, resid, stats, rows, hidden, gamma, thr,
              inv_keep, seed, site, dz_out, dy_out, d_gamma, d_beta, d_bias, partials);
   if (partials) launch_reduce_partials3(partials, g, hidden, d_gamma, d_beta, d_bias, (hipStream_t)stream);
