@@ -274,6 +274,8 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(
     const float* __restrict__ stats, uint32_t thr, float inv_keep, uint32_t seed, uint32_t site,
     const bf16_t* __restrict__ dx, float* d_word, float* d_pos, float* d_type0, float* d_gamma, float* d_beta, float* part) {
   __shared__ float lds_acc[3 * 1024];
+  __shared__ __attribute__((aligned(16))) float tr_all[4][1024];
+  float* tr = tr_all[threadIdx.x >> 6];
   for (int i = threadIdx.x; i < 3 * 1024; i += blockDim.x) lds_acc[i] = 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -321,12 +323,15 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(
       if (c < H) {
         const f32x4 dz = (gh[it] - s1 - xh[it] * s2) * rstd;
         acc[2][it] += dz;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          unsafeAtomicAdd(d_word + (size_t)id * H + c + j, dz[j]);
-          unsafeAtomicAdd(d_pos + (size_t)s * H + c + j, dz[j]);
-        }
+        *(f32x4*)(tr + c) = dz;     // wave-private row image in LDS
       }
+    }
+    // scatter-add with every atomic wave-instruction covering 256 CONTIGUOUS bytes (lane l -> element 64k + l):
+    // four 4-byte adds 16 B apart per lane ran at a quarter of this rate (MI355X float-atomic access shape)
+    for (int c = lane; c < H; c += 64) {
+      const float v = tr[c];
+      unsafeAtomicAdd(d_word + (size_t)id * H + c, v);
+      unsafeAtomicAdd(d_pos + (size_t)s * H + c, v);
     }
   }
   flush_colsums<NIT>(lds_acc, acc, H, lane, d_gamma, d_beta, d_type0, part);
