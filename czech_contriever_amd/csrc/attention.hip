@@ -70,12 +70,13 @@ __device__ __forceinline__ bf16x8 frag_tr(const unsigned char* lds, int rbase, i
   const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, v);
 }
-// registers 8s .. 8s+7 of an accumulator tile as the bf16 operand of k-step s
+// registers 8s .. 8s+7 of an accumulator tile as the bf16 operand of k-step s: a vector conversion compiles to
+// exactly four v_cvt_pk_bf16_f32 (element-wise casts made hipcc add ~4 moves / sdwa ORs per pair; inline asm
+// would hide the VALU-write -> MFMA-read hazard from the compiler and needs manual s_nops)
 __device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s) {
-  bf16x8 f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) f[j] = (__bf16)a[8 * s + j];
-  return f;
+  typedef __attribute__((ext_vector_type(8))) float f32x8;
+  const f32x8 v = {a[8 * s], a[8 * s + 1], a[8 * s + 2], a[8 * s + 3], a[8 * s + 4], a[8 * s + 5], a[8 * s + 6], a[8 * s + 7]};
+  return __builtin_convertvector(v, bf16x8);
 }
 __device__ __forceinline__ bf16x8 ld_frag_global(const bf16_t* p) {
   const uint4 v = *(const uint4*)p;
@@ -184,13 +185,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
           o[0] *= alpha;
           o[1] *= alpha;
         }
-        if (DROP) {
+        if (DROP) {   // drop = select 0; the 1/(1-p) scale is applied once, to the final O
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            float z[4];
-            keep4(rkey, erow + (uint32_t)(kb0 + 32 * tt + 8 * g + 4 * h), a.thr, a.inv_keep, z);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) s[4 * g + j] *= z[j];
+            const czc_quad qd = czc_rng_quad(rkey, (erow + (uint32_t)(kb0 + 32 * tt + 8 * g + 4 * h)) >> 2);
+            s[4 * g + 0] = ((qd.lo & 0xffffu) >= a.thr) ? s[4 * g + 0] : 0.f;
+            s[4 * g + 1] = ((qd.lo >> 16) >= a.thr) ? s[4 * g + 1] : 0.f;
+            s[4 * g + 2] = ((qd.hi & 0xffffu) >= a.thr) ? s[4 * g + 2] : 0.f;
+            s[4 * g + 3] = ((qd.hi >> 16) >= a.thr) ? s[4 * g + 3] : 0.f;
           }
         }
 #pragma unroll
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
   }
   if (!active) return;
   l += __shfl_xor(l, 32, 64);
-  const float inv = 1.0f / l;
+  const float inv = (DROP ? a.inv_keep : 1.0f) / l;
   const int q = q0 + r;
   if (q < S) {
     bf16_t* dst = a.out + ((size_t)b * S + q) * a.H + hh * 64;

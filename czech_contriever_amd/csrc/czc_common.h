@@ -44,7 +44,11 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return __builtin_bit_cast(bf16_t, b);
 }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  // vector conversion = one v_cvt_pk_bf16_f32 (RNE, NaN stays NaN); two scalar casts + shift/or cost 3-4 more ops
+  typedef __attribute__((ext_vector_type(2))) float f32x2_;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+  const f32x2_ v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_));
 }
 __device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
