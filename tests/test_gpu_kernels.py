@@ -316,7 +316,8 @@ def _attn_ref(qkv, mask, B, S, nh, keep=None, p=0.0):
 
 
 @pytest.mark.parametrize("B,S,nh,lengths", [(2, 256, 12, [256, 130]), (5, 24, 2, [24, 17, 1, 9, 24]),
-                                            (3, 100, 4, [100, 64, 33]), (2, 320, 2, [320, 200])])
+                                            (3, 100, 4, [100, 64, 33]), (2, 320, 2, [320, 200]),
+                                            (3, 27, 2, [27, 13, 1]), (2, 1, 1, [1, 1]), (1, 512, 1, [500])])
 def test_attention_fwd_bwd(ops, B, S, nh, lengths):
     H = nh * 64
     qkv = rnd(B * S, 3 * H, seed=1, scale=1.0, dtype=BF16)

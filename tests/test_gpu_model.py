@@ -131,6 +131,27 @@ def test_bert_base_full_depth_vs_oracle(gpu):
     assert float(c.min()) >= 1 - 1e-3, c
 
 
+@pytest.mark.parametrize("B,S,lengths", [(3, 27, [27, 13, 1]), (1, 1, [1]), (2, 64, [64, 2])])
+def test_encoder_odd_shapes_vs_oracle(gpu, B, S, lengths):
+    """sequence lengths that are not multiples of any tile size (the reference pads q and k to the batch maximum,
+    27..130 tokens with the README flags), a single token, and a single sequence"""
+    enc, P, cfg_o = make_encoder(TINY, 9, "average", gpu)
+    enc.eval()
+    ids, mask = ragged_batch(B, S, 10, 512, lengths)
+    for norm in (False, True):
+        Pg = {n: v.clone().requires_grad_(True) for n, v in P.items()}
+        ref = O.encoder_forward(Pg, ids, mask, cfg_o, "average", norm)
+        emb = enc(input_ids=ids.to(gpu), attention_mask=mask.to(gpu), normalize=norm)
+        assert float(cos_rows(emb.detach().cpu(), ref.detach()).min()) >= 1 - 1e-3
+        cot = O.det_uniform((B, cfg_o.hidden_size), 12)
+        (ref * cot).sum().backward()
+        enc.zero_grad()
+        (emb * cot.to(gpu)).sum().backward()
+        got = torch.cat([p.grad.reshape(-1) for p in enc.parameters()]).cpu().double()
+        want = torch.cat([Pg[n].grad.reshape(-1) for n, _ in O.param_names(cfg_o)]).double()
+        assert float(torch.nn.functional.cosine_similarity(got, want, dim=0)) >= 1 - 3e-3
+
+
 def _moco_opt(model_dir, **kw):
     d = dict(queue_size=64, momentum=0.99, temperature=0.05, label_smoothing=0.0, norm_doc=False, norm_query=False,
              moco_train_mode_encoder_k=False, weight_decay=0.01, weight_decay_from_init=False,
