@@ -101,9 +101,16 @@ struct AttnArgs {
   float inv_keep;
 };
 
-// key-padding bias (log2 domain) for the whole (padded) sequence
-__device__ __forceinline__ void load_mask_bias(const AttnArgs& a, int b, float* mb, int spad, int tid) {
-  for (int s = tid; s < spad; s += 256) mb[s] = (s < a.S && a.mask[(size_t)b * a.S + s]) ? 0.f : NEG_MASK;
+// key-padding bias (log2 domain) for the whole (padded) sequence; padflag[t] != 0 iff 32-key tile t holds a masked
+// key (most tiles do not: they take a path without the bias add)
+__device__ __forceinline__ void load_mask_bias(const AttnArgs& a, int b, float* mb, int* padflag, int spad, int tid) {
+  if (tid < 16) padflag[tid] = 0;
+  __syncthreads();
+  for (int s = tid; s < spad; s += 256) {
+    const bool valid = s < a.S && a.mask[(size_t)b * a.S + s];
+    mb[s] = valid ? 0.f : NEG_MASK;
+    if (!valid) padflag[s >> 5] = 1;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -114,6 +121,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char kt[2][64 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char vt[2][64 * 128];
   __shared__ __attribute__((aligned(16))) float mb[512];
+  __shared__ int padflag[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z, hh = blockIdx.y;
   const int S = a.S, H3 = 3 * a.H;
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
   const bool active = q0 < S;  // wave-uniform
   const float c2 = 0.125f * LOG2E;
 
-  load_mask_bias(a, b, mb, spad, tid);
+  load_mask_bias(a, b, mb, padflag, spad, tid);
 
   const bf16_t* base = a.qkv + (size_t)b * S * H3 + hh * 64;
   bf16x8 bq[4];
@@ -159,27 +167,44 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
           s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(kt[buf], 32 * tt, ks, lane), bq[ks], s, 0, 0, 0);
-        float mx = m;
+        float mx, alpha, ps = 0.f;
+        if (padflag[(kb0 >> 5) + tt]) {          // wave-uniform: this tile holds masked keys
+          mx = m;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 bias = *(const f32x4*)(mb + kb0 + 32 * tt + 8 * g + 4 * h);
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 bias = *(const f32x4*)(mb + kb0 + 32 * tt + 8 * g + 4 * h);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float x = s[4 * g + j] * c2 + bias[j];
-            s[4 * g + j] = x;
-            mx = fmaxf(mx, x);
+            for (int j = 0; j < 4; ++j) {
+              const float x = s[4 * g + j] * c2 + bias[j];
+              s[4 * g + j] = x;
+              mx = fmaxf(mx, x);
+            }
+          }
+          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          alpha = __builtin_amdgcn_exp2f(m - mx);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float p = __builtin_amdgcn_exp2f(s[i] - mx);
+            s[i] = p;
+            ps += p;
+          }
+        } else {                                  // no padding: max on the raw scores, one fma + one exp per element
+          float rm = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+          for (int i = 3; i < 15; i += 2) rm = fmaxf(fmaxf(rm, s[i]), s[i + 1]);
+          rm = fmaxf(rm, s[15]);
+          mx = fmaxf(m, rm * c2);
+          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          alpha = __builtin_amdgcn_exp2f(m - mx);
+          const float nmx = -mx;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(s[i], c2, nmx));
+            s[i] = p;
+            ps += p;
           }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float alpha = __builtin_amdgcn_exp2f(m - mx);
         m = mx;
-        float ps = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float p = __builtin_amdgcn_exp2f(s[i] - mx);
-          s[i] = p;
-          ps += p;
-        }
         l = l * alpha + ps;
         if (__any(alpha != 1.0f)) {   // exact: when no row's running max moved, alpha == 1 in every lane
           o[0] *= alpha;
@@ -236,6 +261,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char kt[2][64 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char vt[2][64 * 128];
   __shared__ __attribute__((aligned(16))) float mb[512];
+  __shared__ int padflag[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z, hh = blockIdx.y;
   const int S = a.S, H3 = 3 * a.H;
@@ -245,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
   const bool active = q0 < S;
   const float c2 = 0.125f * LOG2E;
 
-  load_mask_bias(a, b, mb, spad, tid);
+  load_mask_bias(a, b, mb, padflag, spad, tid);
 
   const bf16_t* base = a.qkv + (size_t)b * S * H3 + hh * 64;
   int qr = q0 + r; if (qr > S - 1) qr = S - 1;
@@ -303,9 +329,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
         if (DROP) {
           keep4(rkey, erow + (uint32_t)(kb0 + 32 * tt + 8 * g + 4 * h), a.thr, a.inv_keep, z);
         }
+        const f32x4 bl = bias - lse2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float p = __builtin_amdgcn_exp2f(s[4 * g + j] * c2 + bias[j] - lse2);
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[4 * g + j], c2, bl[j]));
           s[4 * g + j] = p * (z[j] * dp[4 * g + j] - dl);   // dS^T (before the 1/8 scale)
         }
       }
@@ -430,9 +457,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
           for (int g = 0; g < 4; ++g) {
             const f32x4 l4 = *(const f32x4*)(&lse_s[buf][32 * hf + 8 * g + 4 * h]);
             const f32x4 d4 = *(const f32x4*)(&del_s[buf][32 * hf + 8 * g + 4 * h]);
+            const f32x4 kl = kbias - l4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const float p = __builtin_amdgcn_exp2f(s[4 * g + j] * c2 + kbias - l4[j]);
+              const float p = __builtin_amdgcn_exp2f(fmaf(s[4 * g + j], c2, kl[j]));
               float z = 1.f;
               if (DROP) {
                 const uint32_t e = ebase + (uint32_t)(qb0 + 32 * hf + 8 * g + 4 * h + j) * S4;
