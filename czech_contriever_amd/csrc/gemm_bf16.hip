@@ -331,55 +331,52 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
     }
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes are done (region is wave-private)
-  bf16_t* C = (bf16_t*)a.C;
+  // read the staged tile back as 16-B row segments and store them with raw buffer ops: rows beyond M fall outside
+  // the descriptor and columns beyond N get an out-of-range offset, so the loop is branch-free and the LDS reads of
+  // later segments are issued while earlier stores drain
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  const unsigned cbytes = (unsigned)min((size_t)a.M * (size_t)a.ldc * 2u, (size_t)0xfffffff0u);
+  __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, cbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rc2 = __builtin_amdgcn_make_buffer_rsrc(EPI == EPI_BIAS_GELU ? a.C2 : a.C, 0, cbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((EPI == EPI_DGELU || EPI == EPI_ADD) ? (void*)a.aux : a.C, 0, cbytes, 0x00020000);
   float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // DGELU: this lane's 8 columns over its 2*TM rows
-#pragma unroll 4
+#pragma unroll
   for (int it = 0; it < TM * 16 * NCH / 64; ++it) {
     const int idx = it * 64 + lane;
     const int rl = idx / NCH, ch = idx % NCH;
     const int m = row0 + wm * TM * 16 + rl;
     const int n = col0 + wn * WNC + ch * 8;
-    if (m < a.M && n < a.N) {
-      uint4 v = *(const uint4*)(reg + rl * ROWB + ((ch ^ (rl & 7)) << 4));
-      const size_t off = (size_t)m * a.ldc + n;
-      if (EPI == EPI_BIAS_GELU) {
-        *(uint4*)(C + off) = v;
-        uint4 g;
-        g.x = pack2bf(gelu_f(bflo(v.x)), gelu_f(bfhi(v.x)));
-        g.y = pack2bf(gelu_f(bflo(v.y)), gelu_f(bfhi(v.y)));
-        g.z = pack2bf(gelu_f(bflo(v.z)), gelu_f(bfhi(v.z)));
-        g.w = pack2bf(gelu_f(bflo(v.w)), gelu_f(bfhi(v.w)));
-        *(uint4*)((bf16_t*)a.C2 + off) = g;
-      } else if (EPI == EPI_BIAS_GELU1) {
-        uint4 g;
-        g.x = pack2bf(gelu_f(bflo(v.x)), gelu_f(bfhi(v.x)));
-        g.y = pack2bf(gelu_f(bflo(v.y)), gelu_f(bfhi(v.y)));
-        g.z = pack2bf(gelu_f(bflo(v.z)), gelu_f(bfhi(v.z)));
-        g.w = pack2bf(gelu_f(bflo(v.w)), gelu_f(bfhi(v.w)));
-        *(uint4*)(C + off) = g;
-      } else if (EPI == EPI_DGELU) {
-        const uint4 u = *(const uint4*)(a.aux + off);
-        float e[8];
-        e[0] = bflo(v.x) * dgelu_f(bflo(u.x)); e[1] = bfhi(v.x) * dgelu_f(bfhi(u.x));
-        e[2] = bflo(v.y) * dgelu_f(bflo(u.y)); e[3] = bfhi(v.y) * dgelu_f(bfhi(u.y));
-        e[4] = bflo(v.z) * dgelu_f(bflo(u.z)); e[5] = bfhi(v.z) * dgelu_f(bfhi(u.z));
-        e[6] = bflo(v.w) * dgelu_f(bflo(u.w)); e[7] = bfhi(v.w) * dgelu_f(bfhi(u.w));
-        uint4 g;
-        g.x = pack2bf(e[0], e[1]); g.y = pack2bf(e[2], e[3]); g.z = pack2bf(e[4], e[5]); g.w = pack2bf(e[6], e[7]);
-        *(uint4*)(C + off) = g;
+    const unsigned off = (n < a.N) ? (unsigned)(((size_t)m * a.ldc + n) * 2u) : 0xfffffff0u;
+    const u32x4 v = *(const u32x4*)(reg + rl * ROWB + ((ch ^ (rl & 7)) << 4));
+    if (EPI == EPI_BIAS_GELU) {
+      __builtin_amdgcn_raw_buffer_store_b128(v, rc, off, 0, 0);
+      u32x4 g;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) csum[j] += e[j];
-      } else if (EPI == EPI_ADD) {
-        const uint4 u = *(const uint4*)(a.aux + off);
-        uint4 g;
-        g.x = pack2bf(bflo(v.x) + bflo(u.x), bfhi(v.x) + bfhi(u.x));
-        g.y = pack2bf(bflo(v.y) + bflo(u.y), bfhi(v.y) + bfhi(u.y));
-        g.z = pack2bf(bflo(v.z) + bflo(u.z), bfhi(v.z) + bfhi(u.z));
-        g.w = pack2bf(bflo(v.w) + bflo(u.w), bfhi(v.w) + bfhi(u.w));
-        *(uint4*)(C + off) = g;
-      } else {
-        *(uint4*)(C + off) = v;
+      for (int e = 0; e < 4; ++e) g[e] = pack2bf(gelu_f(bflo(v[e])), gelu_f(bfhi(v[e])));
+      __builtin_amdgcn_raw_buffer_store_b128(g, rc2, off, 0, 0);
+    } else if (EPI == EPI_BIAS_GELU1) {
+      u32x4 g;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = pack2bf(gelu_f(bflo(v[e])), gelu_f(bfhi(v[e])));
+      __builtin_amdgcn_raw_buffer_store_b128(g, rc, off, 0, 0);
+    } else if (EPI == EPI_DGELU) {
+      const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0);
+      u32x4 g;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = bflo(v[e]) * dgelu_f(bflo(u[e])), hi = bfhi(v[e]) * dgelu_f(bfhi(u[e]));
+        g[e] = pack2bf(lo, hi);
+        if (m < a.M) { csum[2 * e] += lo; csum[2 * e + 1] += hi; }
       }
+      __builtin_amdgcn_raw_buffer_store_b128(g, rc, off, 0, 0);
+    } else if (EPI == EPI_ADD) {
+      const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0);
+      u32x4 g;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = pack2bf(bflo(v[e]) + bflo(u[e]), bfhi(v[e]) + bfhi(u[e]));
+      __builtin_amdgcn_raw_buffer_store_b128(g, rc, off, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_buffer_store_b128(v, rc, off, 0, 0);
     }
   }
   if (EPI == EPI_DGELU && a.colsum) {
@@ -475,6 +472,9 @@ static int gemm_dispatch_inner(int al, int bl, int epi, GemmArgs a, int splitk, 
   if (al == 1) CZC_REQUIRE((a.M % 8) == 0, "czc_gemm: M=%d must be a multiple of 8 for an M-major A", a.M);
   if (bl == 0) CZC_REQUIRE((a.K % 8) == 0, "czc_gemm: K=%d must be a multiple of 8 for a K-major B", a.K);
   CZC_REQUIRE(splitk >= 1, "czc_gemm: splitk=%d", splitk);
+  if (epi != EPI_F32 && epi != EPI_LSE)
+    CZC_REQUIRE((size_t)a.M * (size_t)a.ldc * 2u < 0xfffffff0ull,
+                "czc_gemm: a bf16 output of %d x %d exceeds the 4 GiB a buffer descriptor addresses", a.M, a.ldc);
   CZC_REQUIRE(splitk == 1 || epi == EPI_F32, "czc_gemm: split-K needs the f32 slab epilogue");
   const int kt = ceil_div(a.K, BK);
   a.ktiles_per_split = ceil_div(kt, splitk);
