@@ -46,9 +46,18 @@ struct Cfg {
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
 
+// 16 B per lane, global -> LDS (destination = dst + 16*lane, dst wave-uniform).  Issued as inline asm on purpose:
+// given the builtin, the compiler tracks the pending LDS DMA and puts an s_waitcnt vmcnt(0) in front of the next
+// ds_read_b64_tr_b16 (it cannot prove that read does not alias the DMA's destination), which exposes the whole
+// global latency once per K-tile in the MN-major kernels.  The K-loop orders the two itself: vmcnt(0) + barrier
+// before a staged buffer is first read.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // m0 is "reserved": it is ours to set here, nothing else in this file uses it
 __device__ __forceinline__ void glds16(const void* src, lptr_t dst) {
-  __builtin_amdgcn_global_load_lds((gptr_t)src, dst, 16, 0, 0);
+  const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)dst);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(l) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 
 // ---- staging -------------------------------------------------------------------------------
 // K-major operand: X[rows][ld], tile = rows [row0, row0+256) x k [k0, k0+64)
@@ -298,27 +307,34 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
 
   // bf16 outputs: registers -> LDS (per-wave 128 x 64 bf16 region, 16-B chunks XOR-swizzled by
   // row&7) -> 16-B row segments -> global
+  // bias / row vector first, as bounds-checked buffer loads (out of range reads 0): all in flight together and
+  // hidden behind the barrier, instead of one dependent load per fragment
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  f32x4 bv[TN];
+  float rvv[TM];
+  if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU1) {
+    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, (unsigned)a.N * 4u, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      bv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)(col0 + wn * WNC + 16 * j + 4 * nq) * 4u, 0, 0));
+  }
+  if (EPI == EPI_SOFTGRAD) {
+    __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)a.rowv, 0, (unsigned)a.M * 4u, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      rvv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (unsigned)(row0 + wm * TM * 16 + 16 * i + mrow) * 4u, 0, 0));
+  }
   __syncthreads();  // all waves are done reading the operand tiles
   constexpr int ROWB = TN * 32, NCH = TN * 2;   // bytes / 16-B chunks per staged row
   unsigned char* reg = smem + wave * (TM * 16 * ROWB);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int rl = 16 * i + mrow;
-    float rv = 0.f;
-    if (EPI == EPI_SOFTGRAD) {
-      const int m = row0 + wm * TM * 16 + rl;
-      rv = (m < a.M) ? a.rowv[m] : 0.f;
-    }
+    const float rv = (EPI == EPI_SOFTGRAD) ? rvv[i] : 0.f;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       f32x4 v = acc[i][j];
-      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU1) {
-        const int n = col0 + wn * WNC + 16 * j + 4 * nq;
-        if (n < a.N) {
-          const f32x4 b = *(const f32x4*)(a.bias + n);
-          v += b;
-        }
-      }
+      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU1) v += bv[j];
       if (EPI == EPI_SOFTGRAD) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = __expf(v[r] * a.alpha - rv) - a.beta;
@@ -334,7 +350,6 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   // read the staged tile back as 16-B row segments and store them with raw buffer ops: rows beyond M fall outside
   // the descriptor and columns beyond N get an out-of-range offset, so the loop is branch-free and the LDS reads of
   // later segments are issued while earlier stores drain
-  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
   const unsigned cbytes = (unsigned)min((size_t)a.M * (size_t)a.ldc * 2u, (size_t)0xfffffff0u);
   __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, cbytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rc2 = __builtin_amdgcn_make_buffer_rsrc(EPI == EPI_BIAS_GELU ? a.C2 : a.C, 0, cbytes, 0x00020000);
