@@ -324,8 +324,24 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
     for (int i = 0; i < TM; ++i)
       rvv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (unsigned)(row0 + wm * TM * 16 + 16 * i + mrow) * 4u, 0, 0));
   }
-  __syncthreads();  // all waves are done reading the operand tiles
+  // the readback below hands lane l of pass `it` the 16-B segment idx = 64*it + l of the wave's 128 x 64 region
   constexpr int ROWB = TN * 32, NCH = TN * 2;   // bytes / 16-B chunks per staged row
+  constexpr int NIT = TM * 16 * NCH / 64;
+  const unsigned cbytes = (unsigned)min((size_t)a.M * (size_t)a.ldc * 2u, (size_t)0xfffffff0u);
+  auto seg_off = [&](int it) -> unsigned {   // byte offset of that segment in C / C2 / aux, out of range past N
+    const int idx = it * 64 + lane;
+    const int m = row0 + wm * TM * 16 + idx / NCH, n = col0 + wn * WNC + (idx % NCH) * 8;
+    return (n < a.N) ? (unsigned)(((size_t)m * a.ldc + n) * 2u) : 0xfffffff0u;
+  };
+  // DGELU / ADD: the second operand's segments, all requested before the barrier (a load issued inside the store
+  // loop would be kept behind the preceding store and pay the full memory latency NIT times over)
+  u32x4 au[NIT];
+  if (EPI == EPI_DGELU || EPI == EPI_ADD) {
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.aux, 0, cbytes, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) au[it] = __builtin_amdgcn_raw_buffer_load_b128(ra, seg_off(it), 0, 0);
+  }
+  __syncthreads();  // all waves are done reading the operand tiles
   unsigned char* reg = smem + wave * (TM * 16 * ROWB);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -350,19 +366,21 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   // read the staged tile back as 16-B row segments and store them with raw buffer ops: rows beyond M fall outside
   // the descriptor and columns beyond N get an out-of-range offset, so the loop is branch-free and the LDS reads of
   // later segments are issued while earlier stores drain
-  const unsigned cbytes = (unsigned)min((size_t)a.M * (size_t)a.ldc * 2u, (size_t)0xfffffff0u);
   __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, cbytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rc2 = __builtin_amdgcn_make_buffer_rsrc(EPI == EPI_BIAS_GELU ? a.C2 : a.C, 0, cbytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((EPI == EPI_DGELU || EPI == EPI_ADD) ? (void*)a.aux : a.C, 0, cbytes, 0x00020000);
   float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // DGELU: this lane's 8 columns over its 2*TM rows
+  u32x4 sv[NIT];
 #pragma unroll
-  for (int it = 0; it < TM * 16 * NCH / 64; ++it) {
+  for (int it = 0; it < NIT; ++it) {
     const int idx = it * 64 + lane;
     const int rl = idx / NCH, ch = idx % NCH;
-    const int m = row0 + wm * TM * 16 + rl;
-    const int n = col0 + wn * WNC + ch * 8;
-    const unsigned off = (n < a.N) ? (unsigned)(((size_t)m * a.ldc + n) * 2u) : 0xfffffff0u;
-    const u32x4 v = *(const u32x4*)(reg + rl * ROWB + ((ch ^ (rl & 7)) << 4));
+    sv[it] = *(const u32x4*)(reg + rl * ROWB + ((ch ^ (rl & 7)) << 4));
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int m = row0 + wm * TM * 16 + (it * 64 + lane) / NCH;
+    const unsigned off = seg_off(it);
+    const u32x4 v = sv[it];
     if (EPI == EPI_BIAS_GELU) {
       __builtin_amdgcn_raw_buffer_store_b128(v, rc, off, 0, 0);
       u32x4 g;
@@ -375,7 +393,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
       for (int e = 0; e < 4; ++e) g[e] = pack2bf(gelu_f(bflo(v[e])), gelu_f(bfhi(v[e])));
       __builtin_amdgcn_raw_buffer_store_b128(g, rc, off, 0, 0);
     } else if (EPI == EPI_DGELU) {
-      const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0);
+      const u32x4 u = au[it];
       u32x4 g;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -385,7 +403,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
       }
       __builtin_amdgcn_raw_buffer_store_b128(g, rc, off, 0, 0);
     } else if (EPI == EPI_ADD) {
-      const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0);
+      const u32x4 u = au[it];
       u32x4 g;
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] = pack2bf(bflo(v[e]) + bflo(u[e]), bfhi(v[e]) + bfhi(u[e]));
