@@ -46,12 +46,6 @@ __device__ __forceinline__ void tile_commit(const TileRegs<ROWS>& t, unsigned ch
     *(uint4*)(lds + row * 128 + ((c ^ swz64(row)) << 4)) = t.v[i];
   }
 }
-// sum over the 32 lanes of each half-wave (lanes that share lane>>5), result in every lane
-__device__ __forceinline__ float half_sum(float v) {
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
 
 // 32x32x16 A/B operand by rows: lane (r = lane&31, h = lane>>5) holds tile[row0 + r][16ks + 8h .. +7]
 __device__ __forceinline__ bf16x8 frag_row(const unsigned char* lds, int row0, int ks, int lane) {
@@ -180,7 +174,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
               mx = fmaxf(mx, x);
             }
           }
-          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          mx = xor32_max(mx);
           alpha = __builtin_amdgcn_exp2f(m - mx);
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
@@ -194,7 +188,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
           for (int i = 3; i < 15; i += 2) rm = fmaxf(fmaxf(rm, s[i]), s[i + 1]);
           rm = fmaxf(rm, s[15]);
           mx = fmaxf(m, rm * c2);
-          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          mx = xor32_max(mx);
           alpha = __builtin_amdgcn_exp2f(m - mx);
           const float nmx = -mx;
 #pragma unroll
@@ -235,7 +229,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
     }
   }
   if (!active) return;
-  l += __shfl_xor(l, 32, 64);
+  l = xor32_sum(l);
   const float inv = (DROP ? a.inv_keep : 1.0f) / l;
   const int q = q0 + r;
   if (q < S) {
@@ -290,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
       for (int j = 0; j < 8; ++j) dl += (float)bdo[ks][j] * (float)of[j];
     }
   }
-  dl += __shfl_xor(dl, 32, 64);
+  dl = xor32_sum(dl);
   const float lse2 = qvalid ? a.lse_in[((size_t)b * a.nh + hh) * S + qr] * LOG2E : 1.0e30f;
   if (active && qvalid && h == 0) a.delta[((size_t)b * a.nh + hh) * S + qr] = dl;
 

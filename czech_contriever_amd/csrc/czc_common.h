@@ -54,16 +54,51 @@ __device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 
 __device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
 // ---- wave (64-lane) reductions ----------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Butterflies on the VALU: DPP lane permutes inside a row of 16 (xor 1, xor 2, then the two mirrors, which add the
+// other quad / the other half-row because every lane of a quad already holds the quad's value) and the gfx950
+// v_permlane16_swap / v_permlane32_swap across rows.  A __shfl_xor is a ds_bpermute_b32: an LDS round trip (tens of
+// cycles, waited for with lgkmcnt) per step, which made row statistics and column sums latency-bound.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+#define CZC_DPP_XOR1 0xB1          // quad_perm [1,0,3,2]
+#define CZC_DPP_XOR2 0x4E          // quad_perm [2,3,0,1]
+#define CZC_DPP_HALF_MIRROR 0x141  // lane i <-> 7 - i within 8
+#define CZC_DPP_MIRROR 0x140       // lane i <-> 15 - i within 16
+// lanes l and l ^ 16 / l ^ 32: both operands of the swap start as v, so afterwards a and b are the two partner values.
+// Inline asm: the __builtin_amdgcn_permlane{16,32}_swap of this toolchain hands back its first result twice.
+// (s_nop 1: the VALU write -> permlane-swap read hazard the compiler would otherwise pad itself)
+__device__ __forceinline__ void xor16_pair(float v, float& a, float& b) {
+  a = v; b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void xor32_pair(float v, float& a, float& b) {
+  a = v; b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float row_sum16(float v) {   // sum over each row of 16 lanes, in every lane of the row
+  v += dpp_mov<CZC_DPP_XOR1>(v);
+  v += dpp_mov<CZC_DPP_XOR2>(v);
+  v += dpp_mov<CZC_DPP_HALF_MIRROR>(v);
+  v += dpp_mov<CZC_DPP_MIRROR>(v);
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row_max16(float v) {
+  v = fmaxf(v, dpp_mov<CZC_DPP_XOR1>(v));
+  v = fmaxf(v, dpp_mov<CZC_DPP_XOR2>(v));
+  v = fmaxf(v, dpp_mov<CZC_DPP_HALF_MIRROR>(v));
+  v = fmaxf(v, dpp_mov<CZC_DPP_MIRROR>(v));
   return v;
 }
+__device__ __forceinline__ float xor16_sum(float v) { float a, b; xor16_pair(v, a, b); return a + b; }
+__device__ __forceinline__ float xor32_sum(float v) { float a, b; xor32_pair(v, a, b); return a + b; }
+__device__ __forceinline__ float xor16_max(float v) { float a, b; xor16_pair(v, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float xor32_max(float v) { float a, b; xor32_pair(v, a, b); return fmaxf(a, b); }
+// sum over the 32 lanes of each half-wave (lanes that share lane>>5), result in every lane
+__device__ __forceinline__ float half_sum(float v) { return xor16_sum(row_sum16(v)); }
+__device__ __forceinline__ float wave_sum(float v) { return xor32_sum(xor16_sum(row_sum16(v))); }
+__device__ __forceinline__ float wave_max(float v) { return xor32_max(xor16_max(row_max16(v))); }
 
 // ---- counter-based dropout RNG -------------------------------------------------------
 // Elements 4i .. 4i+3 of a dropout site share ONE mixed word finished twice (64 bits): 16 bits per element,

@@ -267,15 +267,14 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
           sm += (n + r < a.N) ? z : 0.f;
         }
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = xor32_max(xor16_max(mx));
       float se = 0.f;
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) se += __expf(acc[i][j][r] - mx);
-      se += __shfl_xor(se, 16, 64); se += __shfl_xor(se, 32, 64);
-      sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
+      se = xor32_sum(xor16_sum(se));
+      sm = xor32_sum(xor16_sum(sm));
       if (nq == 0) {
         const int ml = wm * TM * 16 + 16 * i + mrow;
         red[(0 * WN + wn) * BM + ml] = mx;
@@ -416,10 +415,10 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
     // lanes with equal (lane & 7) own the same 8 columns: fold the 8 row groups, then 8 lanes x 8 atomics
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
+      static_assert(NCH == 8, "the fold below pairs lanes l, l^8, l^16, l^32");
       float t = csum[j];
-#pragma unroll
-      for (int o = NCH; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
-      csum[j] = t;
+      t += dpp_mov<0x128>(t);   // row_ror:8 = lane ^ 8 within a row of 16
+      csum[j] = xor32_sum(xor16_sum(t));
     }
     // one partial row per (M-tile, wave row): colsum[(tm * WM + wm)][N], written whole (no atomics)
     const int n = col0 + wn * WNC + (lane % NCH) * 8;
