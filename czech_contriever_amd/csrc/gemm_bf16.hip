@@ -131,14 +131,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   constexpr int BM = CF::BM, BN = CF::BN, TM = CF::TM, TN = CF::TN, WN = CF::WN;
   constexpr int WNC = TN * 16;  // columns per wave
   constexpr int TILE_BYTES_A = CF::TILE_A, BUF_BYTES = CF::BUF;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
 
-  int tm, tn;
-  swizzle_tile(blockIdx.x, gridDim.x, a.tiles_n, tm, tn);
-  const int row0 = tm * BM, col0 = tn * BN;
   const int split = blockIdx.y;
   const int kt_total = (a.K + BK - 1) / BK;
   const int kt_begin = split * a.ktiles_per_split;
@@ -146,21 +139,44 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   if (kt_end > kt_total) kt_end = kt_total;
   const int nt = kt_end - kt_begin;
 
+  // Persistent over output tiles: the workgroup takes tiles blockIdx.x, + gridDim.x, ... (the host launches one
+  // workgroup per resident slot for the bf16 epilogues, one per tile otherwise).  A bf16 epilogue stages through the
+  // second operand buffer only, so the first K-tile of the workgroup's NEXT output tile is already on its way into
+  // the first buffer while this tile is written out: the ~3 us a tile otherwise waits for its first operands
+  // (12 K-tiles of 1.7 us at K = 768) are hidden behind the stores.
+  constexpr bool PREFETCH = (EPI != EPI_F32 && EPI != EPI_LSE);
+  const int ntiles = a.tiles_m * a.tiles_n;
+  bool primed = false;   // K-tile 0 of the coming output tile was requested during the previous epilogue
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // lane-derived addresses are recomputed per tile from an opaque copy of the thread id: hoisted out of the tile loop
+  // they would stay live through the epilogue, where the accumulators, the prefetched second operand and the staged
+  // segments already fill the register file (the hoisted form spilled ~100 dwords per lane and tile)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  auto stage_at = [&](int r0, int c0, int t, int buf) {
+    unsigned char* ta = smem + buf * BUF_BYTES;
+    unsigned char* tb = ta + TILE_BYTES_A;
+    const int k0 = (kt_begin + t) * BK;
+    if (AL == 0) stage_kmajor<BM, CF::NW>(a.A, a.lda, r0, a.M, k0, a.K, ta, wave, lane);
+    else         stage_mnmajor<BM, CF::NW>(a.A, a.lda, r0, a.M, k0, a.K, ta, wave, lane);
+    if (BL == 0) stage_kmajor<BN, CF::NW>(a.B, a.ldb, c0, a.N, k0, a.K, tb, wave, lane);
+    else         stage_mnmajor<BN, CF::NW>(a.B, a.ldb, c0, a.N, k0, a.K, tb, wave, lane);
+  };
+  int tm, tn;
+  swizzle_tile(tile, ntiles, a.tiles_n, tm, tn);
+  const int row0 = tm * BM, col0 = tn * BN;
+  if (!PREFETCH && tile != (int)blockIdx.x) __syncthreads();   // nobody still reads what the first DMA overwrites
+
   f32x4 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  auto stage = [&](int t, int buf) {
-    unsigned char* ta = smem + buf * BUF_BYTES;
-    unsigned char* tb = ta + TILE_BYTES_A;
-    const int k0 = (kt_begin + t) * BK;
-    if (AL == 0) stage_kmajor<BM, CF::NW>(a.A, a.lda, row0, a.M, k0, a.K, ta, wave, lane);
-    else         stage_mnmajor<BM, CF::NW>(a.A, a.lda, row0, a.M, k0, a.K, ta, wave, lane);
-    if (BL == 0) stage_kmajor<BN, CF::NW>(a.B, a.ldb, col0, a.N, k0, a.K, tb, wave, lane);
-    else         stage_mnmajor<BN, CF::NW>(a.B, a.ldb, col0, a.N, k0, a.K, tb, wave, lane);
-  };
+  auto stage = [&](int t, int buf) { stage_at(row0, col0, t, buf); };
 
   // Software pipeline, 4 phases per K-tile (2 k-steps x 2 halves of the wave's rows), one barrier per K-tile.
   // While the MFMAs of one phase run, the LDS reads of the next phase's fragments are in flight:
@@ -191,8 +207,14 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
     acc[(HALF) * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j], FA[i], acc[(HALF) * HM + i][j], 0, 0, 0)
 
   if (nt > 0) {
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // counted wait when primed: the epilogue's stores were issued after that DMA and need not have been acknowledged
+    constexpr int NST = (EPI == EPI_BIAS_GELU ? 2 : 1) * (TM * 16 * TN * 2 / 64);
+    static_assert(NST <= 32, "vmcnt immediate");
+    if (!primed) { stage(0, 0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    else if (NST == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else if (NST == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (NST == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (nt > 1) stage(1, 1);
     read_a(fa0, 0, 0, 0);
@@ -246,7 +268,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
         if (m < a.M && n < a.N) *(f32x4*)(C + (size_t)m * a.ldc + n) = acc[i][j];
       }
     }
-    return;
+    continue;
   }
 
   if (EPI == EPI_LSE) {
@@ -301,10 +323,10 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
         a.part[2 * pl + (size_t)tn * a.M + m] = sm;
       }
     }
-    return;
+    continue;
   }
 
-  // bf16 outputs: registers -> LDS (per-wave 128 x 64 bf16 region, 16-B chunks XOR-swizzled by
+  // bf16 outputs: registers -> LDS (per-wave rows x 64 bf16 region, 16-B chunks XOR-swizzled by
   // row&7) -> 16-B row segments -> global
   // bias / row vector first, as bounds-checked buffer loads (out of range reads 0): all in flight together and
   // hidden behind the barrier, instead of one dependent load per fragment
@@ -341,74 +363,91 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
     for (int it = 0; it < NIT; ++it) au[it] = __builtin_amdgcn_raw_buffer_load_b128(ra, seg_off(it), 0, 0);
   }
   __syncthreads();  // all waves are done reading the operand tiles
-  unsigned char* reg = smem + wave * (TM * 16 * ROWB);
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int rl = 16 * i + mrow;
-    const float rv = (EPI == EPI_SOFTGRAD) ? rvv[i] : 0.f;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      f32x4 v = acc[i][j];
-      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU1) v += bv[j];
-      if (EPI == EPI_SOFTGRAD) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = __expf(v[r] * a.alpha - rv) - a.beta;
-      }
-      uint2 w;
-      w.x = pack2bf(v[0], v[1]);
-      w.y = pack2bf(v[2], v[3]);
-      const int chunk = (2 * j + (nq >> 1)) ^ (rl & 7);
-      *(uint2*)(reg + rl * ROWB + chunk * 16 + (nq & 1) * 8) = w;
-    }
+  // the first operand buffer is free now: request K-tile 0 of this workgroup's next output tile into it
+  if (tile + (int)gridDim.x < ntiles && nt > 0) {
+    int tm2, tn2;
+    swizzle_tile(tile + gridDim.x, ntiles, a.tiles_n, tm2, tn2);
+    stage_at(tm2 * BM, tn2 * BN, 0, 0);
+    primed = true;
+  } else {
+    primed = false;
   }
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes are done (region is wave-private)
-  // read the staged tile back as 16-B row segments and store them with raw buffer ops: rows beyond M fall outside
+  // the tile leaves through the second operand buffer, NPASS slices of the wave's rows at a time
+  constexpr int NPASS = (CF::NW * TM * 16 * ROWB) / BUF_BYTES;
+  static_assert(NPASS >= 1 && TM % NPASS == 0 && NIT % NPASS == 0, "epilogue staging does not tile the operand buffer");
+  constexpr int TMP = TM / NPASS, NITP = NIT / NPASS;
+  unsigned char* reg = smem + BUF_BYTES + wave * (TMP * 16 * ROWB);
+  // read the staged rows back as 16-B row segments and store them with raw buffer ops: rows beyond M fall outside
   // the descriptor and columns beyond N get an out-of-range offset, so the loop is branch-free and the LDS reads of
   // later segments are issued while earlier stores drain
   __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, cbytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rc2 = __builtin_amdgcn_make_buffer_rsrc(EPI == EPI_BIAS_GELU ? a.C2 : a.C, 0, cbytes, 0x00020000);
   float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // DGELU: this lane's 8 columns over its 2*TM rows
-  u32x4 sv[NIT];
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int idx = it * 64 + lane;
-    const int rl = idx / NCH, ch = idx % NCH;
-    sv[it] = *(const u32x4*)(reg + rl * ROWB + ((ch ^ (rl & 7)) << 4));
-  }
+  for (int ps = 0; ps < NPASS; ++ps) {
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int m = row0 + wm * TM * 16 + (it * 64 + lane) / NCH;
-    const unsigned off = seg_off(it);
-    const u32x4 v = sv[it];
-    if (EPI == EPI_BIAS_GELU) {
-      __builtin_amdgcn_raw_buffer_store_b128(v, rc, off, 0, 0);
-      u32x4 g;
+    for (int ii = 0; ii < TMP; ++ii) {
+      const int i = ps * TMP + ii;
+      const int rl = 16 * ii + mrow;   // row inside this pass's slice
+      const float rv = (EPI == EPI_SOFTGRAD) ? rvv[i] : 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] = pack2bf(gelu_f(bflo(v[e])), gelu_f(bfhi(v[e])));
-      __builtin_amdgcn_raw_buffer_store_b128(g, rc2, off, 0, 0);
-    } else if (EPI == EPI_BIAS_GELU1) {
-      u32x4 g;
+      for (int j = 0; j < TN; ++j) {
+        f32x4 v = acc[i][j];
+        if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU1) v += bv[j];
+        if (EPI == EPI_SOFTGRAD) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] = pack2bf(gelu_f(bflo(v[e])), gelu_f(bfhi(v[e])));
-      __builtin_amdgcn_raw_buffer_store_b128(g, rc, off, 0, 0);
-    } else if (EPI == EPI_DGELU) {
-      const u32x4 u = au[it];
-      u32x4 g;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float lo = bflo(v[e]) * dgelu_f(bflo(u[e])), hi = bfhi(v[e]) * dgelu_f(bfhi(u[e]));
-        g[e] = pack2bf(lo, hi);
-        if (m < a.M) { csum[2 * e] += lo; csum[2 * e + 1] += hi; }
+          for (int r = 0; r < 4; ++r) v[r] = __expf(v[r] * a.alpha - rv) - a.beta;
+        }
+        uint2 w;
+        w.x = pack2bf(v[0], v[1]);
+        w.y = pack2bf(v[2], v[3]);
+        const int chunk = (2 * j + (nq >> 1)) ^ (rl & 7);
+        *(uint2*)(reg + rl * ROWB + chunk * 16 + (nq & 1) * 8) = w;
       }
-      __builtin_amdgcn_raw_buffer_store_b128(g, rc, off, 0, 0);
-    } else if (EPI == EPI_ADD) {
-      const u32x4 u = au[it];
-      u32x4 g;
+    }
+    u32x4 sv[NITP];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] = pack2bf(bflo(v[e]) + bflo(u[e]), bfhi(v[e]) + bfhi(u[e]));
-      __builtin_amdgcn_raw_buffer_store_b128(g, rc, off, 0, 0);
-    } else {
-      __builtin_amdgcn_raw_buffer_store_b128(v, rc, off, 0, 0);
+    for (int it = 0; it < NITP; ++it) {
+      const int idx = it * 64 + lane;
+      const int rl = idx / NCH, ch = idx % NCH;
+      sv[it] = *(const u32x4*)(reg + rl * ROWB + ((ch ^ (rl & 7)) << 4));
+    }
+#pragma unroll
+    for (int itp = 0; itp < NITP; ++itp) {
+      const int it = ps * NITP + itp;
+      const int m = row0 + wm * TM * 16 + (it * 64 + lane) / NCH;
+      const unsigned off = seg_off(it);
+      const u32x4 v = sv[itp];
+      if (EPI == EPI_BIAS_GELU) {
+        __builtin_amdgcn_raw_buffer_store_b128(v, rc, off, 0, 0);
+        u32x4 g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = pack2bf(gelu_f(bflo(v[e])), gelu_f(bfhi(v[e])));
+        __builtin_amdgcn_raw_buffer_store_b128(g, rc2, off, 0, 0);
+      } else if (EPI == EPI_BIAS_GELU1) {
+        u32x4 g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = pack2bf(gelu_f(bflo(v[e])), gelu_f(bfhi(v[e])));
+        __builtin_amdgcn_raw_buffer_store_b128(g, rc, off, 0, 0);
+      } else if (EPI == EPI_DGELU) {
+        const u32x4 u = au[it];
+        u32x4 g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = bflo(v[e]) * dgelu_f(bflo(u[e])), hi = bfhi(v[e]) * dgelu_f(bfhi(u[e]));
+          g[e] = pack2bf(lo, hi);
+          if (m < a.M) { csum[2 * e] += lo; csum[2 * e + 1] += hi; }
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(g, rc, off, 0, 0);
+      } else if (EPI == EPI_ADD) {
+        const u32x4 u = au[it];
+        u32x4 g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = pack2bf(bflo(v[e]) + bflo(u[e]), bfhi(v[e]) + bfhi(u[e]));
+        __builtin_amdgcn_raw_buffer_store_b128(g, rc, off, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128(v, rc, off, 0, 0);
+      }
     }
   }
   if (EPI == EPI_DGELU && a.colsum) {
@@ -428,12 +467,14 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
       *(f32x4*)(row + 4) = (f32x4){csum[4], csum[5], csum[6], csum[7]};
     }
   }
+  }  // tile loop
 }
 
 // ---- host launcher ---------------------------------------------------------------------------
 typedef Cfg<2, 4, 8> CfgBig;
 typedef Cfg<2, 2, 4> CfgSmall;
 static int g_tile_override = 0;  // 0 = heuristic, 1 = 256x256, 2 = 128x128
+static bool g_one_wg_per_tile = false;  // tuning knob: switch the persistent tile loop off
 
 template <int AL, int BL, int EPI, class CF>
 static int launch_cfg(GemmArgs a, int splits, hipStream_t st) {
@@ -445,7 +486,20 @@ static int launch_cfg(GemmArgs a, int splits, hipStream_t st) {
   }
   a.tiles_m = ceil_div(a.M, CF::BM);
   a.tiles_n = ceil_div(a.N, CF::BN);
-  dim3 grid(a.tiles_m * a.tiles_n, splits, 1);
+  // bf16 epilogues run persistent (one workgroup per resident slot, see the kernel); the split-K and head-LSE
+  // forms keep one workgroup per tile
+  static int slots = 0;
+  if (!slots) {
+    int dev = 0, cus = 0;
+    CZC_HIP(hipGetDevice(&dev));
+    CZC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    slots = cus * (160 * 1024 / CF::LDS);
+  }
+  const int ntiles = a.tiles_m * a.tiles_n;
+  // (measured, interleaved A/B at 65536 x {768, 2304, 3072}: persistent -1..-3 % for the bias / store / add / dGELU
+  //  epilogues, +2 % for the two-output bias+GELU epilogue, which therefore keeps one workgroup per tile)
+  const bool persistent = (EPI != EPI_F32 && EPI != EPI_LSE && EPI != EPI_BIAS_GELU) && splits == 1 && !g_one_wg_per_tile;
+  dim3 grid(persistent ? min(ntiles, slots) : ntiles, splits, 1);
   hipLaunchKernelGGL(kern, grid, dim3(CF::NT), CF::LDS, st, a);
   CZC_LAUNCH_CHECK();
   return CZC_OK;
@@ -560,8 +614,10 @@ extern "C" int czc_gemm_bf16(int a_layout, int b_layout, int epilogue, int M, in
 }
 
 extern "C" int czc_gemm_set_tile(int cfg) {
-  CZC_REQUIRE(cfg >= 0 && cfg <= 2, "czc_gemm_set_tile: cfg=%d (0 default, 1 = 256x256, 2 = 128x128)", cfg);
-  g_tile_override = cfg;
+  CZC_REQUIRE((cfg & ~16) >= 0 && (cfg & ~16) <= 2,
+              "czc_gemm_set_tile: cfg=%d (0 default, 1 = 256x256, 2 = 128x128; +16 = one workgroup per tile)", cfg);
+  g_tile_override = cfg & ~16;
+  g_one_wg_per_tile = (cfg & 16) != 0;
   return CZC_OK;
 }
 
