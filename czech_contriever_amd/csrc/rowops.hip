@@ -15,6 +15,20 @@ __device__ __forceinline__ f32x4 ld_bf4(const bf16_t* p) {
   const uint2 w = *(const uint2*)p;
   return (f32x4){bflo(w.x), bfhi(w.x), bflo(w.y), bfhi(w.y)};
 }
+// 4 bf16 at column c of a row of H, zeros past the end.  The ADDRESS is clamped and the load is unconditional: a load
+// under `if (c < H)` is waited for before the next one is issued (one memory round trip per chunk and tensor),
+// clamped loads of a row are all in flight together.
+__device__ __forceinline__ f32x4 ld_row4(const bf16_t* row, int c, int H) {
+  const bool ok = c < H;
+  const uint2 w = *(const uint2*)(row + (ok ? c : 0));
+  const f32x4 v = {bflo(w.x), bfhi(w.x), bflo(w.y), bfhi(w.y)};
+  return ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ f32x4 ld_vec4(const float* vec, int c, int H) {
+  const bool ok = c < H;
+  const f32x4 v = *(const f32x4*)(vec + (ok ? c : 0));
+  return ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+}
 __device__ __forceinline__ void st_bf4(bf16_t* p, f32x4 v) {
   uint2 w;
   w.x = pack2bf(v[0], v[1]);
@@ -30,6 +44,18 @@ __device__ __forceinline__ f32x4 drop_scale4(uint32_t seed, uint32_t site, uint3
   s[2] = ((q.hi & 0xffffu) >= thr) ? inv_keep : 0.f;
   s[3] = ((q.hi >> 16) >= thr) ? inv_keep : 0.f;
   return s;
+}
+
+// the same draws as 4 keep bits (bit j = element e + j kept), and back to a scale vector: the LayerNorm backward
+// carries a row's dropout decisions from its first to its second phase in one register instead of twelve
+__device__ __forceinline__ uint32_t drop_bits4(uint32_t seed, uint32_t site, uint32_t e, uint32_t thr) {
+  const czc_quad q = czc_rng_quad(czc_rng_key(seed, site), e >> 2);
+  return ((q.lo & 0xffffu) >= thr ? 1u : 0u) | ((q.lo >> 16) >= thr ? 2u : 0u) |
+         ((q.hi & 0xffffu) >= thr ? 4u : 0u) | ((q.hi >> 16) >= thr ? 8u : 0u);
+}
+__device__ __forceinline__ f32x4 bits_scale4(uint32_t bits, float inv_keep) {
+  return (f32x4){(bits & 1u) ? inv_keep : 0.f, (bits & 2u) ? inv_keep : 0.f, (bits & 4u) ? inv_keep : 0.f,
+                 (bits & 8u) ? inv_keep : 0.f};
 }
 
 struct LnStat { float mean, rstd; };
@@ -62,27 +88,31 @@ __global__ __launch_bounds__(256) void residual_ln_fwd_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     uint32_t thr, float inv_keep, uint32_t seed, uint32_t site, bf16_t* __restrict__ x, float* __restrict__ stats) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 gm[NIT], bt[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    gm[it] = ld_vec4(gamma, (lane + 64 * it) * 4, H);
+    bt[it] = ld_vec4(beta, (lane + 64 * it) * 4, H);
+  }
   for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
     const size_t base = (size_t)row * H;
-    f32x4 z[NIT];
+    f32x4 z[NIT], r[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      z[it] = ld_row4(y + base, (lane + 64 * it) * 4, H);
+      r[it] = ld_row4(resid + base, (lane + 64 * it) * 4, H);
+    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int c = (lane + 64 * it) * 4;
-      z[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (c < H) {
-        f32x4 a = ld_bf4(y + base + c);
-        if (thr) a *= drop_scale4(seed, site, (uint32_t)(base + c), thr, inv_keep);
-        z[it] = a + ld_bf4(resid + base + c);
-      }
+      if (thr) z[it] *= drop_scale4(seed, site, (uint32_t)(base + c), thr, inv_keep);
+      z[it] += r[it];
     }
     const LnStat st = row_stats<NIT>(z, H, lane, eps);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int c = (lane + 64 * it) * 4;
-      if (c < H) {
-        const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
-        st_bf4(x + base + c, (z[it] - st.mean) * st.rstd * g + b);
-      }
+      if (c < H) st_bf4(x + base + c, (z[it] - st.mean) * st.rstd * gm[it] + bt[it]);
     }
     if (lane == 0) { stats[2 * (size_t)row] = st.mean; stats[2 * (size_t)row + 1] = st.rstd; }
   }
@@ -165,7 +195,7 @@ static void launch_reduce_partials(const float* part, int nrows, int row_stride,
 }
 
 template <int NIT>
-__global__ __launch_bounds__(256) void residual_ln_bwd_kernel(
+__global__ __launch_bounds__(256, NIT <= 3 ? 4 : 2) void residual_ln_bwd_kernel(
     const bf16_t* __restrict__ dx, const bf16_t* __restrict__ dx2, const bf16_t* __restrict__ y,
     const bf16_t* __restrict__ resid, const float* __restrict__ stats, int rows, int H,
     const float* __restrict__ gamma, uint32_t thr, float inv_keep, uint32_t seed, uint32_t site,
@@ -188,25 +218,42 @@ __global__ __launch_bounds__(256) void residual_ln_bwd_kernel(
   for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
     const size_t base = (size_t)row * H;
     const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
-    f32x4 xh[NIT], gh[NIT], ds[NIT];
+    f32x4 xh[NIT], gh[NIT], rs_[NIT];
+    uint32_t keep = 0;
     float s1 = 0.f, s2 = 0.f;
+    // every load of the row first (clamped addresses, see ld_row4), then the arithmetic
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int c = (lane + 64 * it) * 4;
-      xh[it] = gh[it] = ds[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (c < H) {
-        f32x4 a = ld_bf4(y + base + c);
-        if (thr) { ds[it] = drop_scale4(seed, site, (uint32_t)(base + c), thr, inv_keep); a *= ds[it]; }
-        const f32x4 z = a + ld_bf4(resid + base + c);
-        xh[it] = (z - mean) * rstd;
-        f32x4 g = ld_bf4(dx + base + c);
-        if (dx2) g += ld_bf4(dx2 + base + c);
-        acc[0][it] += g * xh[it];
-        acc[1][it] += g;
-        gh[it] = g * gm[it];
+      xh[it] = ld_row4(y + base, c, H);
+      rs_[it] = ld_row4(resid + base, c, H);
+      gh[it] = ld_row4(dx + base, c, H);
+    }
+    if (dx2) {
+      f32x4 g2[NIT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { s1 += gh[it][j]; s2 += gh[it][j] * xh[it][j]; }
+      for (int it = 0; it < NIT; ++it) g2[it] = ld_row4(dx2 + base, (lane + 64 * it) * 4, H);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) gh[it] += g2[it];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = (lane + 64 * it) * 4;
+      const bool ok = c < H;
+      f32x4 a = xh[it];
+      if (thr) {
+        const uint32_t kb = drop_bits4(seed, site, (uint32_t)(base + c), thr);
+        keep |= kb << (4 * it);
+        a *= bits_scale4(kb, inv_keep);
       }
+      const f32x4 z = a + rs_[it];
+      xh[it] = ok ? (z - mean) * rstd : (f32x4){0.f, 0.f, 0.f, 0.f};
+      const f32x4 g = gh[it];
+      acc[0][it] += g * xh[it];
+      acc[1][it] += g;
+      gh[it] = g * gm[it];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s1 += gh[it][j]; s2 += gh[it][j] * xh[it][j]; }
     }
     s1 = wave_sum(s1) / (float)H;
     s2 = wave_sum(s2) / (float)H;
@@ -217,7 +264,7 @@ __global__ __launch_bounds__(256) void residual_ln_bwd_kernel(
         const f32x4 dz = (gh[it] - s1 - xh[it] * s2) * rstd;
         st_bf4(dz_out + base + c, dz);
         f32x4 dy = dz;
-        if (thr) dy *= ds[it];
+        if (thr) dy *= bits_scale4(keep >> (4 * it), inv_keep);
         if (thr || dy_out != dz_out) st_bf4(dy_out + base + c, dy);
         acc[2][it] += dy;
       }
