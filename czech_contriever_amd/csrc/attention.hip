@@ -20,6 +20,13 @@
 
 namespace czc {
 
+// value of lane J of each aligned group of four lanes, in all four (DPP quad_perm [J, J, J, J])
+template <int J>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, J * 0x55, 0xf, 0xf, true);
+}
+
+
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr float NEG_MASK = -2.0e30f;  // masked score (log2 domain); running max starts at -1e30
@@ -452,13 +459,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
             const f32x4 l4 = *(const f32x4*)(&lse_s[buf][32 * hf + 8 * g + 4 * h]);
             const f32x4 d4 = *(const f32x4*)(&del_s[buf][32 * hf + 8 * g + 4 * h]);
             const f32x4 kl = kbias - l4;
+            // The draws of (query, keys 4c .. 4c+3) are one RNG quad and those four keys are four adjacent lanes
+            // here: lane (r & 3) = j hashes the quad of query j and the group shares the words with quad-perm DPP
+            // moves -- one hash per lane and 4 queries instead of four.  A lane's own 16-bit draw (r & 3) of a
+            // word pair is compared in place: high half as is, low half shifted up (draw >= thr <=> t >= thr << 16).
+            czc_quad qd = {0u, 0u};
+            if (DROP)
+              qd = czc_rng_quad(rkey, (ebase + (uint32_t)(qb0 + 32 * hf + 8 * g + 4 * h + (r & 3)) * S4) >> 2);
+            const uint32_t qlo[4] = {quad_bcast<0>(qd.lo), quad_bcast<1>(qd.lo), quad_bcast<2>(qd.lo), quad_bcast<3>(qd.lo)};
+            const uint32_t qhi[4] = {quad_bcast<0>(qd.hi), quad_bcast<1>(qd.hi), quad_bcast<2>(qd.hi), quad_bcast<3>(qd.hi)};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const float p = __builtin_amdgcn_exp2f(fmaf(s[4 * g + j], c2, kl[j]));
               float z = 1.f;
               if (DROP) {
-                const uint32_t e = ebase + (uint32_t)(qb0 + 32 * hf + 8 * g + 4 * h + j) * S4;
-                z = czc_draw16(czc_rng_quad(rkey, e >> 2), e & 3u) >= a.thr ? a.inv_keep : 0.f;
+                const uint32_t t = ((r & 2) ? qhi[j] : qlo[j]) << ((r & 1) ? 0 : 16);
+                z = t >= (a.thr << 16) ? a.inv_keep : 0.f;
               }
               const float dpz = z * dp[4 * g + j];
               dp[4 * g + j] = p * (dpz - d4[j]);  // dS
