@@ -55,6 +55,12 @@ class DataParallel(nn.Module):
         for enc in self._encoders:
             enc._range_hooks = [self._reduce_range]
             enc.backward_chunk_layers = chunk_layers if world() > 1 else 0
+        if world() > 1 and torch.cuda.is_available():
+            # The GEMMs' persistent launch sizes its grid to ALL the CUs; with RCCL's kernels holding some of them
+            # during the overlapped gradient all-reduce the last workgroups would start a whole pass late.  One
+            # workgroup per output tile degrades gracefully instead (include/czc.h, czc_gemm_set_tile).
+            from . import lib as L
+            L.check(L.load().czc_gemm_set_tile(16))
         if optimizer is not None:
             self.attach(optimizer)
 

@@ -287,6 +287,39 @@ def test_gemm_epilogues(ops):
     report("add", ops.gemm(A, Bm, epilogue="add", aux=aux), acc.to(BF16).float() + aux.float(), 5e-2, 8e-3)
 
 
+@pytest.mark.parametrize("al,bl", [(0, 0), (0, 1)])
+def test_gemm_workgroups_walking_over_tiles(ops, al, bl):
+    """More output tiles (65 x 5 = 325) than resident workgroups (256): every workgroup of the persistent launch takes a
+    second tile whose first K-tile it requested during the first tile's epilogue.  Must equal the one-workgroup-
+    per-tile launch bit for bit, and the fp32 reference within the bf16 bar, for every bf16 epilogue."""
+    from czech_contriever_amd import lib as L
+    M, N, K = 16600, 1280, 192
+    a, b, A, Bm = _mk(M, N, K, al, bl, 77)
+    bias = rnd(N, seed=78)
+    aux = rnd(M, N, seed=79, dtype=BF16)
+    acc = a.float() @ b.float().t()
+    cases = [("store", {}), ("bias", dict(bias=bias)), ("add", dict(aux=aux)), ("dgelu", dict(aux=aux))]
+    if al == 0 and bl == 0:
+        cases.append(("bias_gelu", dict(bias=bias)))
+    lib = L.load()
+    for epi, kw in cases:
+        outs = []
+        for cfg in (1, 17):   # 256x256 tiles: persistent, then one workgroup per tile
+            L.check(lib.czc_gemm_set_tile(cfg))
+            try:
+                o = ops.gemm(A, Bm, a_layout=al, b_layout=bl, M=M, N=N, K=K, epilogue=epi, **kw)
+            finally:
+                L.check(lib.czc_gemm_set_tile(0))
+            outs.append(o[1] if isinstance(o, tuple) else o)
+        assert torch.equal(outs[0], outs[1]), (epi, (outs[0].float() - outs[1].float()).abs().max())
+        if epi == "store":
+            report("walk store", outs[0], acc, 0.02 * math.sqrt(K) * 0.25 + 1e-2, 8e-3)
+        elif epi == "bias":
+            report("walk bias", outs[0], acc + bias, 5e-2, 8e-3)
+        elif epi == "add":
+            report("walk add", outs[0], acc.to(BF16).float() + aux.float(), 5e-2, 8e-3)
+
+
 def test_gemm_splitk_weight_gradient(ops):
     # dW[N',K'] = dY^T X, reduction over 3000 tokens, split 7 ways, then the slab reduction
     Mtok, No, Ko = 3000, 768, 384
