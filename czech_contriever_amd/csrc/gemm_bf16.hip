@@ -223,11 +223,17 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   // pin the issue order inside each phase: one LDS read, then a few MFMAs, ... (the scheduler otherwise sinks the
   // reads to just before their first use and the MFMA pipe waits out every LDS round trip)
   constexpr int RA = (AL == 0) ? 1 : 2, RB = (BL == 0) ? 1 : 2;   // ds instructions per fragment
+  // K-major fragments (one ds_read_b128 each): reads spread evenly over the phase's MFMAs.  Both operands MN-major
+  // (two transposing reads per fragment, the weight-gradient products): one read per MFMA from the start of the phase,
+  // so the last of them has the rest of the phase to come back (measured A/B on one device: -4.5 % on those products,
+  // +1..4 % on the K-major ones, which therefore keep the even spread).
+  constexpr bool FRONT = (AL == 1 && BL == 1);
 #define CZC_INTERLEAVE(NREADS, NMFMA)                                                      \
   _Pragma("unroll") for (int q_ = 0; q_ < (NREADS); ++q_) {                                 \
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                      \
-    __builtin_amdgcn_sched_group_barrier(0x008, (NMFMA) / (NREADS), 0);                     \
-  }
+    __builtin_amdgcn_sched_group_barrier(0x008, FRONT ? 1 : (NMFMA) / (NREADS), 0);         \
+  }                                                                                         \
+  if (FRONT) __builtin_amdgcn_sched_group_barrier(0x008, (NMFMA) - (NREADS), 0);
   constexpr int NM = HM * TN;  // MFMAs per phase
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
