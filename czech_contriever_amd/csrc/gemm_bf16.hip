@@ -57,39 +57,59 @@ __device__ __forceinline__ void glds16(const void* src, lptr_t dst) {
   const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)dst);
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(l) : "memory", "m0");
 }
+// The same with a position in the instruction stream: `pin` (an MFMA operand) is declared read and written, so the
+// DMA is placed before the MFMAs that consume it, and `after` (an operand of the MFMAs before it, dead afterwards)
+// likewise, so the DMA follows the last of those.  An LDS-DMA piece costs its
+// wave 60-180 issue cycles; eight of them back to back after the barrier left the MFMA pipe idle on both waves of a
+// SIMD, spread between the rows of the last phase they issue under the other wave's MFMAs.
+template <class PIN, class AFTER>
+__device__ __forceinline__ void glds16_pin(const void* src, lptr_t dst, PIN& pin, AFTER& after) {
+  const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)dst);
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off" : "+v"(pin), "+v"(after) : "v"(src), "s"(l) : "memory", "m0");
+}
 #pragma clang diagnostic pop
 
 // ---- staging -------------------------------------------------------------------------------
 // K-major operand: X[rows][ld], tile = rows [row0, row0+256) x k [k0, k0+64)
+template <int ROWS, int NW, class PIN, class AFTER>
+__device__ __forceinline__ void stage_kmajor_piece(const bf16_t* X, int ld, int row0, int nrows, int k0, int kdim,
+                                                   unsigned char* tile, int wave, int lane, int i, PIN& pin, AFTER& after) {
+  constexpr int PER = ROWS / 8 / NW;
+  const int q = wave * PER + i;          // 1-KiB piece: rows 8q .. 8q+7
+  const int r = 8 * q + (lane >> 3);
+  const int c = (lane & 7) ^ ((r >> 1) & 7);
+  const int gr = row0 + r, gk = k0 + c * 8;
+  const void* src = (gr < nrows && gk < kdim) ? (const void*)(X + (size_t)gr * ld + gk) : (const void*)g_zero16;
+  glds16_pin(src, (lptr_t)(tile + q * 1024), pin, after);
+}
 template <int ROWS, int NW>
 __device__ __forceinline__ void stage_kmajor(const bf16_t* X, int ld, int row0, int nrows, int k0, int kdim,
                                              unsigned char* tile, int wave, int lane) {
   constexpr int PER = ROWS / 8 / NW;
+  int nopin = 0, nopin2 = 0;
 #pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int q = wave * PER + i;          // 1-KiB piece: rows 8q .. 8q+7
-    const int r = 8 * q + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
-    const int gr = row0 + r, gk = k0 + c * 8;
-    const void* src = (gr < nrows && gk < kdim) ? (const void*)(X + (size_t)gr * ld + gk) : (const void*)g_zero16;
-    glds16(src, (lptr_t)(tile + q * 1024));
-  }
+  for (int i = 0; i < PER; ++i) stage_kmajor_piece<ROWS, NW>(X, ld, row0, nrows, k0, kdim, tile, wave, lane, i, nopin, nopin2);
 }
 // MN-major operand: X[kdim][ld] (free index contiguous), tile = k [k0,k0+64) x cols [col0, col0+256)
+template <int COLS, int NW, class PIN, class AFTER>
+__device__ __forceinline__ void stage_mnmajor_piece(const bf16_t* X, int ld, int col0, int ncols, int k0, int kdim,
+                                                    unsigned char* tile, int wave, int lane, int i, PIN& pin, AFTER& after) {
+  constexpr int PER = COLS / 128 * 16 / NW;
+  const int q = wave * PER + i;          // piece q: block q>>4, k-rows 4*(q&15) .. +3
+  const int blk = q >> 4;
+  const int kr = 4 * (q & 15) + (lane >> 4);
+  const int ch = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
+  const int gk = k0 + kr, gc = col0 + blk * 128 + ch * 8;
+  const void* src = (gk < kdim && gc < ncols) ? (const void*)(X + (size_t)gk * ld + gc) : (const void*)g_zero16;
+  glds16_pin(src, (lptr_t)(tile + q * 1024), pin, after);
+}
 template <int COLS, int NW>
 __device__ __forceinline__ void stage_mnmajor(const bf16_t* X, int ld, int col0, int ncols, int k0, int kdim,
                                               unsigned char* tile, int wave, int lane) {
   constexpr int PER = COLS / 128 * 16 / NW;
+  int nopin = 0, nopin2 = 0;
 #pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int q = wave * PER + i;          // piece q: block q>>4, k-rows 4*(q&15) .. +3
-    const int blk = q >> 4;
-    const int kr = 4 * (q & 15) + (lane >> 4);
-    const int ch = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
-    const int gk = k0 + kr, gc = col0 + blk * 128 + ch * 8;
-    const void* src = (gk < kdim && gc < ncols) ? (const void*)(X + (size_t)gk * ld + gc) : (const void*)g_zero16;
-    glds16(src, (lptr_t)(tile + q * 1024));
-  }
+  for (int i = 0; i < PER; ++i) stage_mnmajor_piece<COLS, NW>(X, ld, col0, ncols, k0, kdim, tile, wave, lane, i, nopin, nopin2);
 }
 
 // ---- fragment reads --------------------------------------------------------------------------
@@ -177,6 +197,20 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   auto stage = [&](int t, int buf) { stage_at(row0, col0, t, buf); };
+  // piece p of K-tile t's DMA (4 pieces of A, then 4 of B), positioned by `pin` (glds16_pin)
+  constexpr int PER_A = (AL == 0 ? BM / 8 : BM / 128 * 16) / CF::NW, PER_B = (BL == 0 ? BN / 8 : BN / 128 * 16) / CF::NW;
+  auto stage_piece = [&](int t, int buf, int p, bf16x8& pin, bf16x8& after) {
+    unsigned char* ta = smem + buf * BUF_BYTES;
+    unsigned char* tb = ta + TILE_BYTES_A;
+    const int k0 = (kt_begin + t) * BK;
+    if (p < PER_A) {
+      if (AL == 0) stage_kmajor_piece<BM, CF::NW>(a.A, a.lda, row0, a.M, k0, a.K, ta, wave, lane, p, pin, after);
+      else         stage_mnmajor_piece<BM, CF::NW>(a.A, a.lda, row0, a.M, k0, a.K, ta, wave, lane, p, pin, after);
+    } else {
+      if (BL == 0) stage_kmajor_piece<BN, CF::NW>(a.B, a.ldb, col0, a.N, k0, a.K, tb, wave, lane, p - PER_A, pin, after);
+      else         stage_mnmajor_piece<BN, CF::NW>(a.B, a.ldb, col0, a.N, k0, a.K, tb, wave, lane, p - PER_A, pin, after);
+    }
+  };
 
   // Software pipeline, 4 phases per K-tile (2 k-steps x 2 halves of the wave's rows), one barrier per K-tile.
   // While the MFMAs of one phase run, the LDS reads of the next phase's fragments are in flight:
@@ -235,27 +269,47 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   }                                                                                         \
   if (FRONT) __builtin_amdgcn_sched_group_barrier(0x008, (NMFMA) - (NREADS), 0);
   constexpr int NM = HM * TN;  // MFMAs per phase
-  for (int t = 0; t < nt; ++t) {
-    const int buf = t & 1;
-    read_a(fa1, buf, 0, 1);
-    CZC_MFMA_HALF(fa0, fb0, 0);
-    CZC_INTERLEAVE(HM * RA, NM)
-    read_a(fa0, buf, 1, 0);
-    read_b(fb1, buf, 1);
-    CZC_MFMA_HALF(fa1, fb0, 1);
-    CZC_INTERLEAVE(HM * RA + TN * RB, NM)
-    read_a(fa1, buf, 1, 1);
-    CZC_MFMA_HALF(fa0, fb1, 0);
-    CZC_INTERLEAVE(HM * RA, NM)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 2 < nt) stage(t + 2, buf);
-    // (after the last tile these read the other buffer's stale bytes: never used, and it keeps the block branch-free)
-    read_a(fa0, buf ^ 1, 0, 0);
-    read_b(fb0, buf ^ 1, 0);
-    CZC_MFMA_HALF(fa1, fb1, 1);
-    CZC_INTERLEAVE(HM * RA + TN * RB, NM)
+  constexpr int PPR = (PER_A + PER_B) / HM;   // DMA pieces per row of the last phase
+  static_assert((PER_A + PER_B) % HM == 0, "DMA pieces do not divide over the last phase's rows");
+  // STAGE: K-tile t+2 exists.  SPREAD: its DMA pieces go between the rows of the last phase instead of in one burst
+  // after the barrier (measured A/B on one device: -2..-4 % for the input-gradient products, K-major A x MN-major B;
+  // no change for K-major x K-major; the weight-gradient products run out of registers with it)
+  constexpr bool SPREAD = (AL == 0 && BL == 1);
+#define CZC_KTILE(STAGE)                                                                             \
+  {                                                                                                  \
+    const int buf = t & 1;                                                                           \
+    read_a(fa1, buf, 0, 1);                                                                          \
+    CZC_MFMA_HALF(fa0, fb0, 0);                                                                      \
+    CZC_INTERLEAVE(HM * RA, NM)                                                                      \
+    read_a(fa0, buf, 1, 0);                                                                          \
+    read_b(fb1, buf, 1);                                                                             \
+    CZC_MFMA_HALF(fa1, fb0, 1);                                                                      \
+    CZC_INTERLEAVE(HM * RA + TN * RB, NM)                                                            \
+    read_a(fa1, buf, 1, 1);                                                                          \
+    CZC_MFMA_HALF(fa0, fb1, 0);                                                                      \
+    CZC_INTERLEAVE(HM * RA, NM)                                                                      \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                      \
+    __syncthreads();                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);   /* phases 0-2 and phase 3 are scheduled as separate regions */ \
+    if ((STAGE) && !SPREAD) stage(t + 2, buf);                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+    /* (after the last tile these read the other buffer's stale bytes: never used) */               \
+    read_a(fa0, buf ^ 1, 0, 0);                                                                      \
+    read_b(fb0, buf ^ 1, 0);                                                                         \
+    _Pragma("unroll") for (int i = 0; i < HM; ++i) {                                                 \
+      if ((STAGE) && SPREAD) {                                                                       \
+        _Pragma("unroll") for (int pp = 0; pp < PPR; ++pp) stage_piece(t + 2, buf, i * PPR + pp, fa1[i], i ? fa1[i - 1] : fa0x); \
+      }                                                                                              \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
+        acc[HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[HM + i][j], 0, 0, 0); \
+    }                                                                                                \
+    CZC_INTERLEAVE(HM * RA + TN * RB, NM)                                                            \
   }
+  bf16x8 fa0x = {};   // nothing precedes the first row's pieces
+  int t = 0;
+  for (; t + 2 < nt; ++t) CZC_KTILE(true)
+  for (; t < nt; ++t) CZC_KTILE(false)
+#undef CZC_KTILE
 #undef CZC_INTERLEAVE
 #undef CZC_MFMA_HALF
 
