@@ -1,9 +1,11 @@
 // gemm_bf16.hip — bf16 MFMA GEMM for gfx950, fp32 accumulate.
 //
-// One 256x256 output tile per 512-thread workgroup (8 waves as 2(M) x 4(N), 128x64 per wave),
+// One 256x256 output tile at a time per 512-thread workgroup (8 waves as 2(M) x 4(N), 128x64 per wave),
 // K-step 64, v_mfma_f32_16x16x32_bf16.  Operand tiles go HBM -> LDS with global_load_lds_dwordx4
 // (no VGPR staging), double-buffered: the DMA of K-tile t+1 is in flight while tile t is
 // multiplied; one barrier per K-tile.  LDS: 2 buffers x (A 32 KiB + B 32 KiB) = 128 KiB.
+// For the bf16 epilogues a workgroup walks over several output tiles (one workgroup per CU): the
+// epilogue stages through the second buffer while the next tile's first K-tile lands in the first.
 //
 // Each operand may be stored with the reduction index contiguous ("K-major": X[M][K], W[N][K]) or
 // with the free index contiguous ("MN-major": the operand of the weight-gradient and input-
