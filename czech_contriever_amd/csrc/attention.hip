@@ -255,6 +255,147 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward, sequences of at most 256 keys: one 512-thread workgroup per (batch, head) keeps ALL of K and V in LDS
+// (2 x 32 KiB, filled once), so the eight waves (32 queries each) share a single barrier and then sweep the eight
+// 32-key tiles independently -- no per-block barrier, no double buffer, K/V read from HBM once instead of once per
+// 128 queries, and 128 VGPRs = four waves per SIMD (two workgroups per CU).  The loop body is the streaming kernel's.
+// ---------------------------------------------------------------------------------------------
+template <bool DROP>
+__global__ __launch_bounds__(512, 4) void attn_fwd_res_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char kt[256 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char vt[256 * 128];
+  __shared__ __attribute__((aligned(16))) float mb[256];
+  __shared__ int padflag[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, hh = blockIdx.y;
+  const int S = a.S, H3 = 3 * a.H;
+  const int q0 = wave * 32;
+  const int r = lane & 31, h = lane >> 5;
+  const int spad = (S + 31) & ~31;
+  const bool active = q0 < S;  // wave-uniform
+  const float c2 = 0.125f * LOG2E;
+  const bf16_t* base = a.qkv + (size_t)b * S * H3 + hh * 64;
+
+  // K and V rows -> LDS (rows past S are zero: their scores are masked out below)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = tid + 512 * i, row = id >> 3, c = id & 7;
+    uint4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+    if (row < S) {
+      kv = *(const uint4*)(base + a.H + (size_t)row * H3 + c * 8);
+      vv = *(const uint4*)(base + 2 * a.H + (size_t)row * H3 + c * 8);
+    }
+    *(uint4*)(kt + row * 128 + ((c ^ swz64(row)) << 4)) = kv;
+    *(uint4*)(vt + row * 128 + ((c ^ swz64(row)) << 4)) = vv;
+  }
+  if (tid < 8) padflag[tid] = 0;
+  __syncthreads();
+  if (tid < spad) {
+    const bool valid = tid < S && a.mask[(size_t)b * S + tid];
+    mb[tid] = valid ? 0.f : NEG_MASK;
+    if (!valid) padflag[tid >> 5] = 1;
+  }
+  bf16x8 bq[4];
+  {
+    int qr = q0 + r; if (qr > S - 1) qr = S - 1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) bq[ks] = ld_frag_global(base + (size_t)qr * H3 + 16 * ks + 8 * h);
+  }
+  __syncthreads();
+  if (!active) return;
+
+  f32x16 o[2];
+  o[0] = o[1] = (f32x16)(0.f);
+  float m = -1.0e30f, l = 0.f;
+  const uint32_t S4 = (uint32_t)((S + 3) & ~3);
+  const uint32_t rkey = czc_rng_key(a.seed, a.site);
+  const uint32_t erow = DROP ? ((uint32_t)((b * a.nh + hh) * S + (q0 + r)) * S4) : 0u;
+#pragma unroll 1
+  for (int k0 = 0; k0 < spad; k0 += 32) {
+    f32x16 s = (f32x16)(0.f);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(kt, k0, ks, lane), bq[ks], s, 0, 0, 0);
+    float mx, alpha, ps = 0.f;
+    if (padflag[k0 >> 5]) {                    // wave-uniform: this tile holds masked keys
+      mx = m;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bias = *(const f32x4*)(mb + k0 + 8 * g + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float x = s[4 * g + j] * c2 + bias[j];
+          s[4 * g + j] = x;
+          mx = fmaxf(mx, x);
+        }
+      }
+      mx = xor32_max(mx);
+      alpha = __builtin_amdgcn_exp2f(m - mx);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float p = __builtin_amdgcn_exp2f(s[i] - mx);
+        s[i] = p;
+        ps += p;
+      }
+    } else {                                    // no padding: max on the raw scores, one fma + one exp per element
+      float rm = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+      for (int i = 3; i < 15; i += 2) rm = fmaxf(fmaxf(rm, s[i]), s[i + 1]);
+      rm = fmaxf(rm, s[15]);
+      mx = fmaxf(m, rm * c2);
+      mx = xor32_max(mx);
+      alpha = __builtin_amdgcn_exp2f(m - mx);
+      const float nmx = -mx;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[i], c2, nmx));
+        s[i] = p;
+        ps += p;
+      }
+    }
+    m = mx;
+    l = l * alpha + ps;
+    if (__any(alpha != 1.0f)) {   // exact: when no row's running max moved, alpha == 1 in every lane
+      o[0] *= alpha;
+      o[1] *= alpha;
+    }
+    if (DROP) {   // drop = select 0; the 1/(1-p) scale is applied once, to the final O
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const czc_quad qd = czc_rng_quad(rkey, (erow + (uint32_t)(k0 + 8 * g + 4 * h)) >> 2);
+        s[4 * g + 0] = ((qd.lo & 0xffffu) >= a.thr) ? s[4 * g + 0] : 0.f;
+        s[4 * g + 1] = ((qd.lo >> 16) >= a.thr) ? s[4 * g + 1] : 0.f;
+        s[4 * g + 2] = ((qd.hi & 0xffffu) >= a.thr) ? s[4 * g + 2] : 0.f;
+        s[4 * g + 3] = ((qd.hi >> 16) >= a.thr) ? s[4 * g + 3] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16x8 pf = acc_frag(s, s2);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, k0 + 16 * s2, 32 * dt, lane), pf, o[dt], 0, 0, 0);
+    }
+  }
+  l = xor32_sum(l);
+  const float inv = (DROP ? a.inv_keep : 1.0f) / l;
+  const int q = q0 + r;
+  if (q < S) {
+    bf16_t* dst = a.out + ((size_t)b * S + q) * a.H + hh * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 w;
+        w.x = pack2bf(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv);
+        w.y = pack2bf(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        *(uint2*)(dst + 32 * dt + 8 * g + 4 * h) = w;
+      }
+    if (h == 0) a.lse[((size_t)b * a.nh + hh) * S + q] = (m + __log2f(l)) * LN2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward 1: dQ (and delta = rowsum(dO * O)).  One wave = 32 queries, sweeps 64-key blocks.
 // ---------------------------------------------------------------------------------------------
 template <bool DROP>
@@ -560,9 +701,15 @@ extern "C" int czc_attention_forward(const uint16_t* qkv, const uint8_t* mask, i
   a.thr = dropout_p > 0.f ? czc_drop_thr(dropout_p) : 0u;
   a.inv_keep = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f;
   a.seed = seed; a.site = site;
-  dim3 grid(ceil_div(seq, 128), heads, batch);
-  if (a.thr) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  if (seq <= 256) {   // all of K and V fit one workgroup's LDS
+    dim3 grid(1, heads, batch);
+    if (a.thr) hipLaunchKernelGGL(attn_fwd_res_kernel<true>, grid, dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_fwd_res_kernel<false>, grid, dim3(512), 0, (hipStream_t)stream, a);
+  } else {
+    dim3 grid(ceil_div(seq, 128), heads, batch);
+    if (a.thr) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  }
   CZC_LAUNCH_CHECK();
   return CZC_OK;
 }
