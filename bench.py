@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--queue", type=int, default=131072)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="diagnostic only: the headline keeps dropout on")
+    ap.add_argument("--objective", choices=("moco", "inbatch"), default="moco",
+                    help="inbatch = SURVEY §8 row f4 (one encoder, queries and keys both differentiable); not the headline")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -142,7 +144,7 @@ def main():
 
     from czech_contriever_amd import lib as L
     from czech_contriever_amd.parallel import DataParallel
-    from src import moco, utils
+    from src import inbatch, moco, utils
     lib = L.load()
 
     mdir = tempfile.mkdtemp(prefix="czc_bench_")
@@ -153,13 +155,13 @@ def main():
         json.dump(cfg, f)
     opt = make_opt(mdir, args.batch, world, args.queue)
     torch.manual_seed(opt.seed)
-    model = moco.MoCo(opt).to(device)
+    model = (moco.MoCo(opt) if args.objective == "moco" else inbatch.InBatch(opt)).to(device)
     model.train()
     optimizer, scheduler = utils.set_optim(opt, model)
     model = DataParallel(model, optimizer)
     batches = synthetic_batches(rank, args.batch, args.seq, 16, device)
     if rank == 0:
-        log(f"model on {device}, {sum(p.numel() for p in model.module.encoder_q.parameters())/1e6:.1f} M params/encoder; warm-up {args.warmup}")
+        log(f"model on {device}, {sum(p.numel() for p in model.module.get_encoder().parameters())/1e6:.1f} M params/encoder; warm-up {args.warmup}")
 
     def step(i):
         loss, _ = model(**batches[i % len(batches)], stats_prefix="train")
@@ -212,7 +214,10 @@ def main():
         if os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
-        headline = (args.batch == 256 and args.seq == 256 and args.queue == 131072 and not args.no_dropout)
+        headline = (args.batch == 256 and args.seq == 256 and args.queue == 131072 and not args.no_dropout
+                    and args.objective == "moco")
+        # in-batch: q fwd+bwd and k fwd+bwd = 6 encoder forwards' worth (275.4 G) + a 2*B*W*B*768 score product
+        flop_per_pair = FLOP_PER_PAIR if args.objective == "moco" else 6 * 45.902e9 * (args.seq / 256.0)
         out = {
             "metric": "contrastive pairs/sec (seq256, bsz256/GPU, queue131k)",
             "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -220,10 +225,12 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "MoCo CZERT (bert-base-sized) bf16, chunk_length=256, per_gpu_batch_size=256, "
                                    "queue_size=131072, temperature=0.05" if headline else
-                                   f"NON-HEADLINE diagnostic: batch={args.batch} seq={args.seq} queue={args.queue} dropout={not args.no_dropout}",
+                                   f"NON-HEADLINE diagnostic: objective={args.objective} batch={args.batch} seq={args.seq} queue={args.queue} dropout={not args.no_dropout}",
                        "global_batch": args.batch * world, "seq_len": args.seq, "queue_size": args.queue,
                        "parallelism": f"dp{world}", "weights": "random-init bert-base (seed 0)", "dropout": 0.0 if args.no_dropout else 0.1,
-                       "step": "q fwd+bwd, EMA, k fwd, InfoNCE fwd+bwd, all-gather+enqueue, grad all-reduce, AdamW"},
+                       "step": "q fwd+bwd, EMA, k fwd, InfoNCE fwd+bwd, all-gather+enqueue, grad all-reduce, AdamW"
+                               if args.objective == "moco" else
+                               "q fwd+bwd, k fwd+bwd (same encoder), key all-gather with grad, in-batch CE, grad all-reduce, AdamW"},
             "roofline": {"bound": "mfma", "achieved": None if kern_tflops is None else round(kern_tflops, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": None if kern_tflops is None else round(kern_tflops / PEAK_BF16_TFLOPS, 4),
@@ -231,10 +238,10 @@ def main():
                          "kernel": "czc::gemm_kernel<0,0,2> FFN-up x.W1^T + bias -> (u, gelu(u)), "
                                    f"M={M} N={N} K={K}, {2.0 * M * N * K / 1e9:.1f} GFLOP/launch",
                          "kernel_ms": round(kern_ms, 4), "launches_timed": cnt.value,
-                         "whole_step_frac": round(value * FLOP_PER_PAIR / (world * PEAK_BF16_TFLOPS * 1e12), 4)},
+                         "whole_step_frac": round(value * flop_per_pair / (world * PEAK_BF16_TFLOPS * 1e12), 4)},
             "final_loss": round(float(last.detach()), 4),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.objective == "moco":
             out["cpu_baseline"] = cpu_baseline(args.seq)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -94,6 +94,7 @@ class FlatBertEncoder(nn.Module):
         self._mirror = None
         self._mirror_version = -1
         self._ws: Dict[tuple, torch.Tensor] = {}
+        self._ws_pool: Dict[tuple, list] = {}
         self._scratch = None
         self._call = 0
         self._anchor = None
@@ -143,6 +144,7 @@ class FlatBertEncoder(nn.Module):
                 self._flat_grad = None
                 self._mirror = None
                 self._ws.clear()
+                self._ws_pool.clear()
                 self._scratch = None
                 self._anchor = None
             self._mirror_version = -1
@@ -201,6 +203,39 @@ class FlatBertEncoder(nn.Module):
             self._ws[key] = ws
         return ws
 
+    def _lease_activations(self, B, S, stamp):
+        """Activation workspace for a forward whose backward is still to come.  Normally ONE buffer per shape, reused
+        every step.  A second differentiable forward of the same encoder before the first backward (the in-batch
+        objective encodes queries AND keys with one encoder, src/inbatch.py:64-65) gets a second buffer; with both out,
+        the older one is taken over -- its forward was abandoned (no backward came), or its backward will say so."""
+        for shape in [k for k in self._ws_pool if k != (B, S)]:   # other shapes: keep only buffers still awaiting a backward
+            self._ws_pool[shape] = [e for e in self._ws_pool[shape] if e["out"]]
+            if not self._ws_pool[shape]:
+                del self._ws_pool[shape]
+        pending = sorted(((e["stamp"], k) for k, v in self._ws_pool.items() if k != (B, S) for e in v))
+        for stamp, k in pending[:-2]:   # forwards of other shapes never backpropagated: forget all but the two newest
+            self._ws_pool[k] = [e for e in self._ws_pool[k] if e["stamp"] != stamp]
+            if not self._ws_pool[k]:
+                del self._ws_pool[k]
+        bufs = self._ws_pool.setdefault((B, S), [])
+        if not bufs:
+            bufs.append({"ws": self._workspace(B, S, True), "stamp": 0, "out": False})
+        pick = next((e for e in bufs if not e["out"]), None)
+        if pick is None and len(bufs) < 2:
+            pick = {"ws": torch.empty_like(bufs[0]["ws"]), "stamp": 0, "out": False}
+            bufs.append(pick)
+        if pick is None:
+            pick = min(bufs, key=lambda e: e["stamp"])
+        pick["stamp"], pick["out"] = stamp, True
+        return pick["ws"]
+
+    def _activations_entry(self, ws):
+        for bufs in self._ws_pool.values():
+            for e in bufs:
+                if e["ws"] is ws:
+                    return e
+        return None
+
     def _bwd_scratch(self, B, S):
         n = int(L.load().czc_encoder_backward_scratch_bytes(C.byref(self._shape), B, S))
         if self._scratch is None or self._scratch.numel() < n:
@@ -235,9 +270,9 @@ class FlatBertEncoder(nn.Module):
 
     def _forward_impl(self, ids, mask, normalize, save):
         B, S = ids.shape
-        ws = self._workspace(B, S, save)
-        emb = torch.empty(B, self.config.hidden_size, dtype=F32, device=ids.device)
         self._call += 1
+        ws = self._lease_activations(B, S, self._call) if save else self._workspace(B, S, False)
+        emb = torch.empty(B, self.config.hidden_size, dtype=F32, device=ids.device)
         seed = (torch.initial_seed() * 2654435761 + self._call * 40503 + id(self) % 9973) & 0xFFFFFFFF
         L.check(L.load().czc_encoder_forward(
             C.byref(self._shape), self._flat.data_ptr(), self.mirror().data_ptr(), ids.data_ptr(), mask.data_ptr(),
@@ -289,10 +324,14 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_emb):
         enc = ctx.enc
-        if ctx.stamp != enc._call and enc._ws.get((ctx.ids.shape[0], ctx.ids.shape[1], 1)) is ctx.ws:
-            # a later forward of the same shape has reused the activation workspace
-            raise RuntimeError("encoder backward after a newer forward of the same shape: activations were overwritten")
-        enc._backward_impl(ctx.ids, ctx.mask, ctx.normalize, ctx.seed, ctx.ws, d_emb.to(F32), ctx.training)
+        entry = enc._activations_entry(ctx.ws)
+        if entry is None or entry["stamp"] != ctx.stamp:
+            raise RuntimeError("encoder backward after newer forwards of the same shape: activations were overwritten "
+                               "(at most two differentiable forwards of one encoder may be pending)")
+        try:
+            enc._backward_impl(ctx.ids, ctx.mask, ctx.normalize, ctx.seed, ctx.ws, d_emb.to(F32), ctx.training)
+        finally:
+            entry["out"] = False
         return torch.zeros_like(d_emb[:1, 0]), None, None, None, None
 
 

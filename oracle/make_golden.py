@@ -41,9 +41,10 @@ def import_reference():
     import src.moco as rm  # noqa
     import src.utils as ru  # noqa
     import src.dist_utils as rd  # noqa
+    import src.inbatch as ri  # noqa
     assert rc.__file__.startswith(REF), rc.__file__
     sys.path.remove(REF)
-    return rc, rm, ru, rd
+    return rc, rm, ru, rd, ri
 
 
 def hf_config(cfg: O.BertShape):
@@ -269,13 +270,36 @@ def g_trace(rc, rm, ru, name="g8_moco_trace.npz", norm=False, ls=0.0):
          wk_probe=m.encoder_k.state_dict()["encoder.layer.1.output.dense.weight"][::7, ::5])
 
 
+def g_inbatch(rc, ri):
+    """Reference InBatch.forward (src/inbatch.py:59-90) on a tiny encoder, dropout off: loss, stats and the gradient
+    of every encoder parameter (queries AND keys go through the same encoder)."""
+    cfg = O.BertShape(**TINY)
+    P = O.make_params(cfg, 31)
+    q_ids, q_mask = ragged_batch(6, 24, 32, cfg.vocab_size, [24, 17, 5, 9, 24, 12])
+    k_ids, k_mask = ragged_batch(6, 20, 33, cfg.vocab_size, [20, 11, 7, 20, 3, 16])
+    out = {"q_ids": q_ids, "q_mask": q_mask, "k_ids": k_ids, "k_mask": k_mask, "seed": 31}
+    for tag, norm, temp, ls in (("plain", False, 1.0, 0.0), ("norm", True, 0.05, 0.1)):
+        enc = ref_encoder(rc, cfg, P, "average")
+        opt = argparse.Namespace(norm_doc=norm, norm_query=norm, label_smoothing=ls, temperature=temp)
+        m = ri.InBatch(opt, retriever=enc, tokenizer=object())
+        loss, stats = m(q_tokens=q_ids, q_mask=q_mask, k_tokens=k_ids, k_mask=k_mask, stats_prefix="train", iter_stats={})
+        loss.backward()
+        out[f"{tag}_cfg"] = np.array([float(norm), temp, ls])
+        out[f"{tag}_loss"] = loss.detach()
+        out[f"{tag}_stats"] = np.array([float(stats["train/loss"][0]), float(stats["train/accuracy"][0]),
+                                        float(stats["train/stdq"][0]), float(stats["train/stdk"][0])])
+        for n, p in enc.named_parameters():
+            out[f"{tag}_grad::{n}"] = p.grad
+    save("g10_inbatch.npz", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    rc, rm, ru, rd = import_reference()
+    rc, rm, ru, rd, ri = import_reference()
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     jobs = {
         "g1": lambda: g_encoder(rc, "g1_tiny_encoder.npz", TINY, 11, 5, 24, [24, 17, 1, 9, 24]),
@@ -289,6 +313,7 @@ def main():
         "g7": lambda: g_grads(rc, "g7_tiny_grads.npz", TINY, 11, 5, 24, [24, 17, 1, 9, 24]),
         "g8": lambda: g_trace(rc, rm, ru),
         "g9": lambda: g_trace(rc, rm, ru, "g9_moco_trace_norm.npz", norm=True, ls=0.1),
+        "g10": lambda: g_inbatch(rc, ri),
     }
     for k, fn in jobs.items():
         if a.only and k not in a.only.split(","):

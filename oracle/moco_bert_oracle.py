@@ -28,6 +28,7 @@ reference inherits through `class Contriever(BertModel)`, src/contriever.py:11-1
   enqueue()           src/moco.py:272-287 (with gather_nograd = identity at world size 1,
                       src/dist_utils.py:31-32; rank-order concat at world size W)
   step_stats()        src/moco.py:340-351
+  inbatch_loss()      src/inbatch.py:59-90 (row f4: one encoder for queries and keys, in-batch negatives)
   warmup_linear()     src/utils.py:99-118
   adamw_step()        src/utils.py:137-150 -> torch.optim.AdamW semantics (decoupled decay)
 """
@@ -250,6 +251,16 @@ def infonce_loss(q, k, queue, temperature, label_smoothing=0.0):
 def step_stats(logits, q, k):
     acc = 100.0 * (logits.argmax(dim=-1) == 0).float().mean()
     return acc, torch.std(q, dim=0).mean(), torch.std(k, dim=0).mean()
+
+
+def inbatch_loss(qemb, kemb_all_ranks, rank, local_bsz, temperature, label_smoothing=0.0):
+    """In-batch negatives (src/inbatch.py:59-90): scores[i, j] = (q_i / T) . k_j over the keys of ALL ranks
+    concatenated in rank order, the positive of local query i is column rank * local_bsz + i."""
+    labels = torch.arange(qemb.shape[0]) + rank * local_bsz
+    scores = (qemb / temperature) @ kemb_all_ranks.t()
+    loss = F.cross_entropy(scores, labels, label_smoothing=label_smoothing)
+    acc = 100.0 * (scores.argmax(dim=-1) == labels).float().mean()
+    return loss, acc, scores
 
 
 def ema_update(Pk, Pq, momentum):

@@ -222,6 +222,47 @@ def test_moco_micro_steps_vs_reference_trace(golden_dir, gpu, tmp_path, name, no
     assert float((wk - t(g["wk_probe"])).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("tag,ltol", [("plain", 2e-2), ("norm", 1e-2)])
+def test_inbatch_vs_reference(golden_dir, gpu, tmp_path, tag, ltol):
+    """`InBatch` (one encoder embeds queries AND keys, both differentiable; positives on the diagonal)
+    against what the reference's src/inbatch.py produced on the same weights and batches (g10): loss, the four
+    stats, and the gradient of every encoder parameter after the two backward passes have accumulated."""
+    from src import inbatch
+    g = load(golden_dir, "g10_inbatch.npz")
+    norm, temp, ls = (float(x) for x in g[f"{tag}_cfg"])
+    mdir = _write_cfg(tmp_path / "tiny", TINY, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    opt = _moco_opt(mdir, norm_query=bool(norm), norm_doc=bool(norm), label_smoothing=ls, temperature=temp)
+    model = inbatch.InBatch(opt)
+    P = O.make_params(O.BertShape(**TINY), int(g["seed"]))
+    model.encoder.load_state_dict(P)
+    model = model.cuda()
+    model.train()
+    loss, stats = model(t(g["q_ids"]).to(gpu), t(g["q_mask"]).to(gpu), t(g["k_ids"]).to(gpu), t(g["k_mask"]).to(gpu),
+                        stats_prefix="train", iter_stats={})
+    loss.backward()
+    ref = g[f"{tag}_stats"]
+    assert abs(float(loss) - float(ref[0])) < ltol * max(1.0, abs(float(ref[0]))), (float(loss), float(ref[0]))
+    assert float(stats["train/accuracy"][0]) == float(ref[1])
+    assert abs(float(stats["train/stdq"][0]) - float(ref[2])) < 5e-3
+    assert abs(float(stats["train/stdk"][0]) - float(ref[3])) < 5e-3
+    gmax = max(float(t(g[f"{tag}_grad::{n}"]).abs().max()) for n in P)
+    num = den_a = den_b = 0.0
+    for n, p in model.encoder.named_parameters():
+        r = t(g[f"{tag}_grad::{n}"]).double()
+        got = p.grad.detach().cpu().double()
+        scale = max(float(r.abs().max()), 0.01 * gmax)
+        assert float((got - r).abs().max()) <= 0.05 * scale, (tag, n, float((got - r).abs().max()), scale)
+        num += float((got * r).sum()); den_a += float((got * got).sum()); den_b += float((r * r).sum())
+    assert num / (den_a ** 0.5 * den_b ** 0.5) > 0.998
+    # a second step reuses both activation buffers (no growth) and accumulates on top
+    n_bufs = sum(len(v) for v in model.encoder._ws_pool.values())
+    loss2, _ = model(t(g["q_ids"]).to(gpu), t(g["q_mask"]).to(gpu), t(g["k_ids"]).to(gpu), t(g["k_mask"]).to(gpu))
+    loss2.backward()
+    assert sum(len(v) for v in model.encoder._ws_pool.values()) == n_bufs
+    w = model.encoder.get_parameter("encoder.layer.1.output.dense.weight")
+    assert torch.allclose(w.grad.cpu(), 2 * t(g[f"{tag}_grad::encoder.layer.1.output.dense.weight"]), atol=0.1 * gmax)
+
+
 def test_moco_checkpoint_layout_roundtrip(gpu, tmp_path):
     from src import moco, utils
     mdir = _write_cfg(tmp_path / "tiny", TINY)

@@ -134,3 +134,25 @@ def test_moco_trace_matches_reference(golden_dir, name, norm, ls):
     assert torch.allclose(st.queue, t(g["queue_final"]), atol=1e-4)
     assert torch.allclose(st.Pq["encoder.layer.1.output.dense.weight"].detach()[::7, ::5], t(g["wq_probe"]), atol=1e-5)
     assert torch.allclose(st.Pk["encoder.layer.1.output.dense.weight"][::7, ::5], t(g["wk_probe"]), atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["plain", "norm"])
+def test_inbatch_matches_reference(golden_dir, tag):
+    """the reference's InBatch.forward (src/inbatch.py:59-90), one encoder for queries and keys."""
+    g = load(golden_dir, "g10_inbatch.npz")
+    cfg = O.BertShape(**TINY)
+    norm, temp, ls = (float(x) for x in g[f"{tag}_cfg"])
+    P = {n: v.requires_grad_(True) for n, v in O.make_params(cfg, int(g["seed"])).items()}
+    q = O.encoder_forward(P, t(g["q_ids"]), t(g["q_mask"]), cfg, "average", bool(norm))
+    k = O.encoder_forward(P, t(g["k_ids"]), t(g["k_mask"]), cfg, "average", bool(norm))
+    loss, acc, _ = O.inbatch_loss(q, k, 0, k.shape[0], temp, ls)
+    loss.backward()
+    ref = g[f"{tag}_stats"]
+    assert abs(float(loss) - float(ref[0])) < 2e-5 * max(1.0, abs(float(ref[0])))
+    assert float(acc) == float(ref[1])
+    assert abs(float(torch.std(q, dim=0).mean()) - float(ref[2])) < 1e-5
+    assert abs(float(torch.std(k, dim=0).mean()) - float(ref[3])) < 1e-5
+    for n, p in P.items():
+        r = t(g[f"{tag}_grad::{n}"])
+        scale = max(1e-6, float(r.abs().max()))
+        assert float((p.grad - r).abs().max()) <= 3e-4 * scale + 1e-6, (tag, n)

@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 import torch
 import torch.distributed as dist
 
-from src import dist_utils, moco, utils
+from src import dist_utils, inbatch, moco, utils
 from src.options import Options
 
 logger = logging.getLogger(__name__)
@@ -156,9 +156,12 @@ def main(argv=None):
     utils.init_logger(opt)
     os.environ["TOKENIZERS_PARALLELISM"] = "false"
 
-    if opt.contrastive_mode != "moco":
-        raise ValueError(f"contrastive_mode: {opt.contrastive_mode} is outside the MI355X path (moco only)")
-    model_class = moco.MoCo
+    if opt.contrastive_mode == "moco":        # reference train.py:449-454
+        model_class = moco.MoCo
+    elif opt.contrastive_mode == "inbatch":
+        model_class = inbatch.InBatch
+    else:
+        raise ValueError(f"contrastive_mode: {opt.contrastive_mode} not recognised")
 
     if not directory_exists and opt.model_path == "none":
         model = model_class(opt).cuda()
