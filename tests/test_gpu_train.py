@@ -62,6 +62,27 @@ def test_train_cli_runs_saves_and_resumes(tmp_path, monkeypatch):
     assert torch.equal(enc.state_dict()["encoder.layer.0.output.dense.weight"], w6)
 
 
+def test_train_cli_inbatch_mode(tmp_path, monkeypatch):
+    """--contrastive_mode inbatch (reference train.py:451-452) through the same loop: checkpoint keys are `encoder.*`."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import train
+    mdir = _cfg_dir(tmp_path)
+    out = str(tmp_path / "run_inbatch")
+    args = ["--retriever_model_id", mdir, "--random_init", "--output_dir", out, "--save_dir", out,
+            "--contrastive_mode", "inbatch", "--chunk_length", "32", "--per_gpu_batch_size", "8",
+            "--target_batch_size", "8", "--temperature", "0.05", "--lr", "1e-3", "--warmup_steps", "1",
+            "--total_steps", "3", "--save_freq", "3", "--log_freq", "1", "--norm_query", "--norm_doc"]
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    train.main(args)
+    ck = torch.load(os.path.join(out, "checkpoint", "step-3", "checkpoint.pth"), map_location="cpu", weights_only=False)
+    assert ck["step"] == 3
+    keys = list(ck["model"].keys())
+    assert all(k.startswith("encoder.") for k in keys) and "encoder.encoder.layer.1.output.dense.weight" in keys
+    assert ck["optimizer"]["state"][0]["step"] == 3
+
+
 def test_weight_decay_from_init_matches_oracle(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")

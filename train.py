@@ -60,7 +60,7 @@ def make_batches(opt, model, rank, world):
     if opt.train_data:
         from src import data_min
         return data_min.loader(opt, core.tokenizer, rank, world)
-    return SyntheticPairs(opt, rank, core.encoder_q.config.vocab_size)
+    return SyntheticPairs(opt, rank, core.get_encoder().config.vocab_size)
 
 
 def train(opt, model, optimizer, scheduler, step):
@@ -97,7 +97,7 @@ def train(opt, model, optimizer, scheduler, step):
             lr = scheduler.get_last_lr()[0]
             log += f" | lr: {lr:0.3g}"
             log += f" | Memory: {torch.cuda.max_memory_allocated() // 1e9} GiB"
-            enc = (model.module if hasattr(model, "module") else model).encoder_q
+            enc = (model.module if hasattr(model, "module") else model).get_encoder()
             g = enc.flat_grads(create=False)
             if g is not None:
                 if hasattr(model, "wait"):
