@@ -47,14 +47,24 @@ def make_opt(model_dir, batch, world, queue):
         per_gpu_batch_size=batch, target_batch_size=batch * world, chunk_length=256, seed=0)
 
 
-def synthetic_batches(rank, batch, seq, n, device):
+def synthetic_batches(rank, batch, seq, n, device, ragged=False):
+    """SURVEY §8 d2.  Headline: all-true masks at `seq`.  ragged: per-sample lengths as the reference's crops produce
+    them -- int(seq * U[0.1, 0.5]) + 2 tokens (src/data.py:553-560, 635-652) -- each side padded with id 0 to ITS OWN
+    batch maximum (src/data.py:563-573), so queries and keys have different widths."""
     out = []
     for t in range(n):
         g = torch.Generator().manual_seed(1234 + 1000 * rank + t)
-        q = torch.randint(1000, 30522, (batch, seq), generator=g, dtype=torch.int64)
-        k = torch.randint(1000, 30522, (batch, seq), generator=g, dtype=torch.int64)
-        m = torch.ones(batch, seq, dtype=torch.bool)
-        out.append(dict(q_tokens=q.to(device), q_mask=m.to(device), k_tokens=k.to(device), k_mask=m.to(device)))
+        sides = []
+        for _ in range(2):
+            ids = torch.randint(1000, 30522, (batch, seq), generator=g, dtype=torch.int64)
+            m = torch.ones(batch, seq, dtype=torch.bool)
+            if ragged:
+                lens = (seq * (0.1 + 0.4 * torch.rand(batch, generator=g))).to(torch.int64) + 2
+                width = int(lens.max())
+                m = torch.arange(width)[None, :] < lens[:, None]
+                ids = ids[:, :width] * m
+            sides.append((ids.to(device), m.to(device)))
+        out.append(dict(q_tokens=sides[0][0], q_mask=sides[0][1], k_tokens=sides[1][0], k_mask=sides[1][1]))
     return out
 
 
@@ -128,6 +138,8 @@ def main():
     ap.add_argument("--queue", type=int, default=131072)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="diagnostic only: the headline keeps dropout on")
+    ap.add_argument("--ragged", action="store_true",
+                    help="informational: sample lengths as the reference's random crops give them (27..130 of 256), pad id 0")
     ap.add_argument("--objective", choices=("moco", "inbatch"), default="moco",
                     help="inbatch = SURVEY §8 row f4 (one encoder, queries and keys both differentiable); not the headline")
     args = ap.parse_args()
@@ -159,7 +171,7 @@ def main():
     model.train()
     optimizer, scheduler = utils.set_optim(opt, model)
     model = DataParallel(model, optimizer)
-    batches = synthetic_batches(rank, args.batch, args.seq, 16, device)
+    batches = synthetic_batches(rank, args.batch, args.seq, 16, device, ragged=args.ragged)
     if rank == 0:
         log(f"model on {device}, {sum(p.numel() for p in model.module.get_encoder().parameters())/1e6:.1f} M params/encoder; warm-up {args.warmup}")
 
@@ -215,7 +227,7 @@ def main():
             with open(tpath) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
         headline = (args.batch == 256 and args.seq == 256 and args.queue == 131072 and not args.no_dropout
-                    and args.objective == "moco")
+                    and args.objective == "moco" and not args.ragged)
         # in-batch: q fwd+bwd and k fwd+bwd = 6 encoder forwards' worth (275.4 G) + a 2*B*W*B*768 score product
         flop_per_pair = FLOP_PER_PAIR if args.objective == "moco" else 6 * 45.902e9 * (args.seq / 256.0)
         out = {
@@ -225,7 +237,7 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "MoCo CZERT (bert-base-sized) bf16, chunk_length=256, per_gpu_batch_size=256, "
                                    "queue_size=131072, temperature=0.05" if headline else
-                                   f"NON-HEADLINE diagnostic: objective={args.objective} batch={args.batch} seq={args.seq} queue={args.queue} dropout={not args.no_dropout}",
+                                   f"NON-HEADLINE diagnostic: objective={args.objective} batch={args.batch} seq={args.seq} ragged={args.ragged} queue={args.queue} dropout={not args.no_dropout}",
                        "global_batch": args.batch * world, "seq_len": args.seq, "queue_size": args.queue,
                        "parallelism": f"dp{world}", "weights": "random-init bert-base (seed 0)", "dropout": 0.0 if args.no_dropout else 0.1,
                        "step": "q fwd+bwd, EMA, k fwd, InfoNCE fwd+bwd, all-gather+enqueue, grad all-reduce, AdamW"
@@ -238,7 +250,7 @@ def main():
                          "kernel": "czc::gemm_kernel<0,0,2> FFN-up x.W1^T + bias -> (u, gelu(u)), "
                                    f"M={M} N={N} K={K}, {2.0 * M * N * K / 1e9:.1f} GFLOP/launch",
                          "kernel_ms": round(kern_ms, 4), "launches_timed": cnt.value,
-                         "whole_step_frac": round(value * flop_per_pair / (world * PEAK_BF16_TFLOPS * 1e12), 4)},
+                         "whole_step_frac": None if args.ragged else round(value * flop_per_pair / (world * PEAK_BF16_TFLOPS * 1e12), 4)},
             "final_loss": round(float(last.detach()), 4),
         }
         if world == 1 and not args.no_cpu_baseline and args.objective == "moco":
