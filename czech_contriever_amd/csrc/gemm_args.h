@@ -15,6 +15,7 @@ struct GemmArgs {
   int lda, ldb, ldc;
   int tiles_m, tiles_n;
   int ktiles_per_split;  // K tiles handled by one split
+  int fast_addr;         // both operands span < 2 GiB: DMA pieces may use 32-bit lane offsets from a scalar base
   int cfg;               // tile configuration: 0 = default, 1 = 256x256 (8 waves), 2 = 128x128 (4 waves, 2 WG/CU)
   float alpha;           // head: 1/T
   float beta;            // head: eps/(K+1)

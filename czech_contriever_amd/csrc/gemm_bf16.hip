@@ -69,7 +69,31 @@ __device__ __forceinline__ void glds16_pin(const void* src, lptr_t dst, PIN& pin
   const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)dst);
   asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off" : "+v"(pin), "+v"(after) : "v"(src), "s"(l) : "memory", "m0");
 }
+// The same from a wave-uniform 64-bit base (SGPRs) plus a 32-bit per-lane byte offset: the offsets of a workgroup's
+// DMA pieces do not change along K, only the base does, so the K-loop spends scalar adds instead of ~13 vector
+// instructions per piece on addresses (stamps: the eight pieces after the barrier took a wave 650-1250 cycles of a
+// 3400-cycle K-tile).
+template <class PIN, class AFTER>
+__device__ __forceinline__ void glds16_sbase(unsigned off, const void* base, lptr_t dst, PIN& pin, AFTER& after) {
+  const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)dst);
+  asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3" : "+v"(pin), "+v"(after) : "v"(off), "s"(base), "s"(l) : "memory", "m0");
+}
 #pragma clang diagnostic pop
+
+// per-lane byte offset of DMA piece i of a full, interior tile, relative to (operand base + the K-tile's advance)
+template <int ROWS, int NW>
+__device__ __forceinline__ unsigned piece_off_kmajor(int ld, int row0, int wave, int lane, int i) {
+  constexpr int PER = ROWS / 8 / NW;
+  const int q = wave * PER + i, r = 8 * q + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+  return (unsigned)(((size_t)(row0 + r) * ld + c * 8) * 2);
+}
+template <int COLS, int NW>
+__device__ __forceinline__ unsigned piece_off_mnmajor(int ld, int col0, int wave, int lane, int i) {
+  constexpr int PER = COLS / 128 * 16 / NW;
+  const int q = wave * PER + i, blk = q >> 4, kr = 4 * (q & 15) + (lane >> 4);
+  const int ch = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
+  return (unsigned)(((size_t)kr * ld + col0 + blk * 128 + ch * 8) * 2);
+}
 
 // ---- staging -------------------------------------------------------------------------------
 // K-major operand: X[rows][ld], tile = rows [row0, row0+256) x k [k0, k0+64)
@@ -198,9 +222,42 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  auto stage = [&](int t, int buf) { stage_at(row0, col0, t, buf); };
   // piece p of K-tile t's DMA (4 pieces of A, then 4 of B), positioned by `pin` (glds16_pin)
   constexpr int PER_A = (AL == 0 ? BM / 8 : BM / 128 * 16) / CF::NW, PER_B = (BL == 0 ? BN / 8 : BN / 128 * 16) / CF::NW;
+  // interior tiles of matrices that fit 32-bit byte offsets take the scalar-base addressing (glds16_sbase) for their
+  // full K-tiles; edge tiles, a ragged last K-tile and huge matrices keep the bounds-checked per-lane pointers
+  // (measured A/B: -6 % for the weight-gradient products, both operands MN-major; +3..9 % for K-major operands, whose
+  //  kernels therefore do not compile it in)
+  constexpr bool USE_FAST = (AL == 1 && BL == 1);
+  const bool fast = USE_FAST && a.fast_addr && row0 + BM <= a.M && col0 + BN <= a.N;
+  unsigned off_a[PER_A], off_b[PER_B];
+#pragma unroll
+  for (int i = 0; i < PER_A; ++i)
+    off_a[i] = (AL == 0) ? piece_off_kmajor<BM, CF::NW>(a.lda, row0, wave, lane, i) : piece_off_mnmajor<BM, CF::NW>(a.lda, row0, wave, lane, i);
+#pragma unroll
+  for (int i = 0; i < PER_B; ++i)
+    off_b[i] = (BL == 0) ? piece_off_kmajor<BN, CF::NW>(a.ldb, col0, wave, lane, i) : piece_off_mnmajor<BN, CF::NW>(a.ldb, col0, wave, lane, i);
+  auto fast_piece = [&](int t, int buf, int p, auto& pin, auto& after) {
+    const int k0 = (kt_begin + t) * BK;
+    if (p < PER_A) {
+      const char* base = (const char*)a.A + ((AL == 0) ? (size_t)k0 * 2 : (size_t)k0 * a.lda * 2);
+      glds16_sbase(off_a[p], base, (lptr_t)(smem + buf * BUF_BYTES + (wave * PER_A + p) * 1024), pin, after);
+    } else {
+      const char* base = (const char*)a.B + ((BL == 0) ? (size_t)k0 * 2 : (size_t)k0 * a.ldb * 2);
+      glds16_sbase(off_b[p - PER_A], base, (lptr_t)(smem + buf * BUF_BYTES + TILE_BYTES_A + (wave * PER_B + p - PER_A) * 1024), pin, after);
+    }
+  };
+  // K-tiles [0, ntf) of this split are full ones and may take the scalar-base form; at most the last one is ragged
+  const int ntf = fast ? max(0, min(nt, a.K / BK - kt_begin)) : 0;
+  auto stage_fast = [&](int t, int buf) {
+    int nopin = 0, nopin2 = 0;
+#pragma unroll
+    for (int p = 0; p < PER_A + PER_B; ++p) fast_piece(t, buf, p, nopin, nopin2);
+  };
+  auto stage = [&](int t, int buf) {
+    if (USE_FAST && t < ntf) stage_fast(t, buf);
+    else stage_at(row0, col0, t, buf);
+  };
   auto stage_piece = [&](int t, int buf, int p, bf16x8& pin, bf16x8& after) {
     unsigned char* ta = smem + buf * BUF_BYTES;
     unsigned char* tb = ta + TILE_BYTES_A;
@@ -277,7 +334,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   // after the barrier (measured A/B on one device: -2..-4 % for the input-gradient products, K-major A x MN-major B;
   // no change for K-major x K-major; the weight-gradient products run out of registers with it)
   constexpr bool SPREAD = (AL == 0 && BL == 1);
-#define CZC_KTILE(STAGE)                                                                             \
+#define CZC_KTILE(STAGE, FAST)                                                                       \
   {                                                                                                  \
     const int buf = t & 1;                                                                           \
     read_a(fa1, buf, 0, 1);                                                                          \
@@ -293,14 +350,17 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                      \
     __syncthreads();                                                                                 \
     __builtin_amdgcn_sched_barrier(0);   /* phases 0-2 and phase 3 are scheduled as separate regions */ \
-    if ((STAGE) && !SPREAD) stage(t + 2, buf);                                                       \
+    if ((STAGE) && !SPREAD) { if (FAST) stage_fast(t + 2, buf); else stage_at(row0, col0, t + 2, buf); } \
     __builtin_amdgcn_sched_barrier(0);                                                               \
     /* (after the last tile these read the other buffer's stale bytes: never used) */               \
     read_a(fa0, buf ^ 1, 0, 0);                                                                      \
     read_b(fb0, buf ^ 1, 0);                                                                         \
     _Pragma("unroll") for (int i = 0; i < HM; ++i) {                                                 \
       if ((STAGE) && SPREAD) {                                                                       \
-        _Pragma("unroll") for (int pp = 0; pp < PPR; ++pp) stage_piece(t + 2, buf, i * PPR + pp, fa1[i], i ? fa1[i - 1] : fa0x); \
+        _Pragma("unroll") for (int pp = 0; pp < PPR; ++pp) {                                         \
+          if (FAST) fast_piece(t + 2, buf, i * PPR + pp, fa1[i], i ? fa1[i - 1] : fa0x);               \
+          else stage_piece(t + 2, buf, i * PPR + pp, fa1[i], i ? fa1[i - 1] : fa0x);                   \
+        }                                                                                            \
       }                                                                                              \
       _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
         acc[HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[HM + i][j], 0, 0, 0); \
@@ -309,8 +369,9 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   }
   bf16x8 fa0x = {};   // nothing precedes the first row's pieces
   int t = 0;
-  for (; t + 2 < nt; ++t) CZC_KTILE(true)
-  for (; t < nt; ++t) CZC_KTILE(false)
+  if (USE_FAST) { for (; t + 2 < ntf; ++t) CZC_KTILE(true, USE_FAST) }
+  for (; t + 2 < nt; ++t) CZC_KTILE(true, false)
+  for (; t < nt; ++t) CZC_KTILE(false, false)
 #undef CZC_KTILE
 #undef CZC_INTERLEAVE
 #undef CZC_MFMA_HALF
@@ -556,6 +617,11 @@ static int launch_cfg(GemmArgs a, int splits, hipStream_t st) {
     CZC_HIP(hipGetDevice(&dev));
     CZC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     slots = cus * (160 * 1024 / CF::LDS);
+  }
+  {
+    const size_t ea = (AL == 0) ? (size_t)a.M * a.lda : (size_t)a.K * a.lda;   // elements spanned by A / B
+    const size_t eb = (BL == 0) ? (size_t)a.N * a.ldb : (size_t)a.K * a.ldb;
+    a.fast_addr = (ea * 2 < (1ull << 31) && eb * 2 < (1ull << 31)) ? 1 : 0;
   }
   const int ntiles = a.tiles_m * a.tiles_n;
   // (measured, interleaved A/B at 65536 x {768, 2304, 3072}: persistent -1..-3 % for the bias / store / add / dGELU
