@@ -226,9 +226,11 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   constexpr int PER_A = (AL == 0 ? BM / 8 : BM / 128 * 16) / CF::NW, PER_B = (BL == 0 ? BN / 8 : BN / 128 * 16) / CF::NW;
   // interior tiles of matrices that fit 32-bit byte offsets take the scalar-base addressing (glds16_sbase) for their
   // full K-tiles; edge tiles, a ragged last K-tile and huge matrices keep the bounds-checked per-lane pointers
-  // (measured A/B: -6 % for the weight-gradient products, both operands MN-major; +3..9 % for K-major operands, whose
-  //  kernels therefore do not compile it in)
-  constexpr bool USE_FAST = (AL == 1 && BL == 1);
+  // (measured A/B: scalar base + lane offset: -6 % for the weight-gradient products, both operands MN-major, but
+  //  +3..9 % with a K-major operand; those add the offset to the base on the VALU instead)
+  // (measured A/B: -2..-5 % everywhere except the dGELU epilogue kernel, which runs out of registers with it: +5 %)
+  constexpr bool USE_FAST = (EPI != EPI_DGELU);
+  constexpr bool SADDR = (AL == 1 && BL == 1);   // else: the same offsets added to the base on the VALU (2 instructions per piece)
   const bool fast = USE_FAST && a.fast_addr && row0 + BM <= a.M && col0 + BN <= a.N;
   unsigned off_a[PER_A], off_b[PER_B];
 #pragma unroll
@@ -241,10 +243,12 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
     const int k0 = (kt_begin + t) * BK;
     if (p < PER_A) {
       const char* base = (const char*)a.A + ((AL == 0) ? (size_t)k0 * 2 : (size_t)k0 * a.lda * 2);
-      glds16_sbase(off_a[p], base, (lptr_t)(smem + buf * BUF_BYTES + (wave * PER_A + p) * 1024), pin, after);
+      if (SADDR) glds16_sbase(off_a[p], base, (lptr_t)(smem + buf * BUF_BYTES + (wave * PER_A + p) * 1024), pin, after);
+      else glds16_pin(base + off_a[p], (lptr_t)(smem + buf * BUF_BYTES + (wave * PER_A + p) * 1024), pin, after);
     } else {
       const char* base = (const char*)a.B + ((BL == 0) ? (size_t)k0 * 2 : (size_t)k0 * a.ldb * 2);
-      glds16_sbase(off_b[p - PER_A], base, (lptr_t)(smem + buf * BUF_BYTES + TILE_BYTES_A + (wave * PER_B + p - PER_A) * 1024), pin, after);
+      if (SADDR) glds16_sbase(off_b[p - PER_A], base, (lptr_t)(smem + buf * BUF_BYTES + TILE_BYTES_A + (wave * PER_B + p - PER_A) * 1024), pin, after);
+      else glds16_pin(base + off_b[p - PER_A], (lptr_t)(smem + buf * BUF_BYTES + TILE_BYTES_A + (wave * PER_B + p - PER_A) * 1024), pin, after);
     }
   };
   // K-tiles [0, ntf) of this split are full ones and may take the scalar-base form; at most the last one is ragged
