@@ -97,6 +97,38 @@ __device__ __forceinline__ unsigned piece_off_mnmajor(int ld, int col0, int wave
 
 // ---- staging -------------------------------------------------------------------------------
 // K-major operand: X[rows][ld], tile = rows [row0, row0+256) x k [k0, k0+64)
+// 1-KiB piece q of a K-major tile: rows 8q .. 8q+7
+template <class PIN, class AFTER>
+__device__ __forceinline__ void stage_kmajor_q(const bf16_t* X, int ld, int row0, int nrows, int k0, int kdim,
+                                               unsigned char* tile, int q, int lane, PIN& pin, AFTER& after) {
+  const int r = 8 * q + (lane >> 3);
+  const int c = (lane & 7) ^ ((r >> 1) & 7);
+  const int gr = row0 + r, gk = k0 + c * 8;
+  const void* src = (gr < nrows && gk < kdim) ? (const void*)(X + (size_t)gr * ld + gk) : (const void*)g_zero16;
+  glds16_pin(src, (lptr_t)(tile + q * 1024), pin, after);
+}
+// 1-KiB piece q of an MN-major tile: block q>>4 (128 columns), k-rows 4*(q&15) .. +3
+template <class PIN, class AFTER>
+__device__ __forceinline__ void stage_mnmajor_q(const bf16_t* X, int ld, int col0, int ncols, int k0, int kdim,
+                                                unsigned char* tile, int q, int lane, PIN& pin, AFTER& after) {
+  const int blk = q >> 4;
+  const int kr = 4 * (q & 15) + (lane >> 4);
+  const int ch = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
+  const int gk = k0 + kr, gc = col0 + blk * 128 + ch * 8;
+  const void* src = (gk < kdim && gc < ncols) ? (const void*)(X + (size_t)gk * ld + gc) : (const void*)g_zero16;
+  glds16_pin(src, (lptr_t)(tile + q * 1024), pin, after);
+}
+// byte offsets of those pieces for interior tiles (see piece_off_*): relative to operand base + the K-tile's advance
+__device__ __forceinline__ unsigned piece_off_kmajor_q(int ld, int row0, int q, int lane) {
+  const int r = 8 * q + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+  return (unsigned)(((size_t)(row0 + r) * ld + c * 8) * 2);
+}
+__device__ __forceinline__ unsigned piece_off_mnmajor_q(int ld, int col0, int q, int lane) {
+  const int blk = q >> 4, kr = 4 * (q & 15) + (lane >> 4);
+  const int ch = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
+  return (unsigned)(((size_t)kr * ld + col0 + blk * 128 + ch * 8) * 2);
+}
+
 template <int ROWS, int NW, class PIN, class AFTER>
 __device__ __forceinline__ void stage_kmajor_piece(const bf16_t* X, int ld, int row0, int nrows, int k0, int kdim,
                                                    unsigned char* tile, int wave, int lane, int i, PIN& pin, AFTER& after) {
@@ -171,7 +203,7 @@ __device__ __forceinline__ void swizzle_tile(int bid, int nwg, int tiles_n, int&
   tn = swz - tm * tiles_n;
 }
 
-template <int AL, int BL, int EPI, class CF>
+template <int AL, int BL, int EPI, class CF, bool PP = false>
 __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BM = CF::BM, BN = CF::BN, TM = CF::TM, TN = CF::TN, WN = CF::WN;
@@ -303,6 +335,167 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                     \
     acc[(HALF) * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j], FA[i], acc[(HALF) * HM + i][j], 0, 0, 0)
 
+  if constexpr (PP) {
+  // ---------------------------------------------------------------------------------------------------------------
+  // Ping-pong K-loop.  The waves form two groups, G0 = waves 0-3 (wm = 0) and G1 = waves 4-7 (wm = 1): one wave of
+  // each per SIMD.  A K-tile is four quadrant phases (64 x 32 outputs x K = 64: 16 MFMAs); a phase is
+  //     LOAD: this quadrant's fragment reads + two LDS-DMA pieces      | s_barrier |
+  //     MFMA: the 16 MFMAs                                              | s_barrier |
+  // and G1 runs one barrier behind G0, so on every SIMD one wave's MFMA cluster covers the other wave's LDS round
+  // trip and DMA issue -- the two never stall together (stamps of the plain loop: a K-tile took 3400 cycles for 2048
+  // of MFMA work; both waves of a SIMD issued DMA / waited at the same points).
+  // LDS: two K-tile buffers, each refilled by HALF operand tiles (128 rows, 16 pieces, 2 per wave) as soon as
+  // every wave's last read of that half has retired and a further barrier has passed:
+  //   segment of tile t   G0 does                      G1 does
+  //   s0                  LOAD Q0 + DMA A0(t+1)        MFMA Q3(t-1)
+  //   s1                  MFMA Q0                      LOAD Q0 + DMA A1(t+1)
+  //   s2                  LOAD Q1 + DMA A1(t+1)        MFMA Q0
+  //   s3                  MFMA Q1                      LOAD Q1 + DMA B1(t+1)     (last B reads of tile t)
+  //   s4                  LOAD Q2 + DMA B1(t+1)        MFMA Q1                   (last A0 reads of tile t)
+  //   s5                  MFMA Q2                      LOAD Q2 + DMA B0(t+2)     (last A1 reads; B of tile t is free)
+  //   s6                  LOAD Q3 + DMA B0(t+2)        MFMA Q2                   (A0 of tile t is free)
+  //   s7                  MFMA Q3, vmcnt(2)            LOAD Q3 + DMA A0(t+2), vmcnt(4)
+  // Q0 = rows lo x cols lo (reads A lo, B lo), Q1 = lo x hi (B hi), Q2 = hi x hi (A hi), Q3 = hi x lo (B lo kept).
+  // The counted waits leave exactly the pieces of tile t+2 in flight: everything of tile t+1 has landed before the
+  // barrier that ends s7, one segment before its first read.
+  static_assert(CF::NW == 8 && TM == 8 && TN == 4, "the ping-pong schedule is written for the 256x256 / 8-wave tile");
+  const int grp = wm;
+  auto stage_half = [&](int r0, int c0, int opnd, int t, int h) {   // this wave's two pieces of half h of A (0) / B (1)
+    unsigned char* ta = smem + (t & 1) * BUF_BYTES;
+    unsigned char* tb = ta + TILE_BYTES_A;
+    const int k0 = (kt_begin + t) * BK;
+    int np = 0, np2 = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = 16 * h + 2 * wave + i;
+      if (opnd == 0) {
+        if (AL == 0) stage_kmajor_q(a.A, a.lda, r0, a.M, k0, a.K, ta, q, lane, np, np2);
+        else         stage_mnmajor_q(a.A, a.lda, r0, a.M, k0, a.K, ta, q, lane, np, np2);
+      } else {
+        if (BL == 0) stage_kmajor_q(a.B, a.ldb, c0, a.N, k0, a.K, tb, q, lane, np, np2);
+        else         stage_mnmajor_q(a.B, a.ldb, c0, a.N, k0, a.K, tb, q, lane, np, np2);
+      }
+    }
+  };
+  // interior tiles: piece offsets fixed along K (see fast_piece above), index [2*h + i]
+  unsigned poff_a[4], poff_b[4];
+#pragma unroll
+  for (int hi = 0; hi < 4; ++hi) {
+    const int q = 16 * (hi >> 1) + 2 * wave + (hi & 1);
+    poff_a[hi] = (AL == 0) ? piece_off_kmajor_q(a.lda, row0, q, lane) : piece_off_mnmajor_q(a.lda, row0, q, lane);
+    poff_b[hi] = (BL == 0) ? piece_off_kmajor_q(a.ldb, col0, q, lane) : piece_off_mnmajor_q(a.ldb, col0, q, lane);
+  }
+  const bool pfast = a.fast_addr && row0 + BM <= a.M && col0 + BN <= a.N;
+  const int pntf = pfast ? max(0, min(nt, a.K / BK - kt_begin)) : 0;   // K-tiles [0, pntf) are full
+  auto stage_half_fast = [&](int opnd, int t, int h) {
+    const int k0 = (kt_begin + t) * BK;
+    int np = 0, np2 = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = 16 * h + 2 * wave + i;
+      if (opnd == 0) {
+        const char* base = (const char*)a.A + ((AL == 0) ? (size_t)k0 * 2 : (size_t)k0 * a.lda * 2);
+        lptr_t dst = (lptr_t)(smem + (t & 1) * BUF_BYTES + q * 1024);
+        if (AL == 1 && BL == 1) glds16_sbase(poff_a[2 * h + i], base, dst, np, np2);
+        else glds16_pin(base + poff_a[2 * h + i], dst, np, np2);
+      } else {
+        const char* base = (const char*)a.B + ((BL == 0) ? (size_t)k0 * 2 : (size_t)k0 * a.ldb * 2);
+        lptr_t dst = (lptr_t)(smem + (t & 1) * BUF_BYTES + TILE_BYTES_A + q * 1024);
+        if (AL == 1 && BL == 1) glds16_sbase(poff_b[2 * h + i], base, dst, np, np2);
+        else glds16_pin(base + poff_b[2 * h + i], dst, np, np2);
+      }
+    }
+  };
+  auto sh = [&](int opnd, int t, int h) {
+    if (t < pntf) stage_half_fast(opnd, t, h);
+    else if (t < nt) stage_half(row0, col0, opnd, t, h);
+  };
+  bf16x8 fa[8], fbl[4], fbh[4];   // A: [ks*4 + i] of the current row half; B lo / hi column pairs: [ks*2 + j]
+  auto load_a = [&](int t, int qi) {
+    const unsigned char* ta = smem + (t & 1) * BUF_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        fa[ks * 4 + i] = (AL == 0) ? frag_kmajor(ta, wm * TM * 16, 4 * qi + i, ks, lane) : frag_mnmajor(ta, wm * TM * 16, 4 * qi + i, ks, lane);
+  };
+  auto load_b = [&](bf16x8 (&fb)[4], int t, int qj) {
+    const unsigned char* tb = smem + (t & 1) * BUF_BYTES + TILE_BYTES_A;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        fb[ks * 2 + j] = (BL == 0) ? frag_kmajor(tb, wn * WNC, 2 * qj + j, ks, lane) : frag_mnmajor(tb, wn * WNC, 2 * qj + j, ks, lane);
+  };
+#define CZC_BAR() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#define CZC_QUAD(QI, QJ, FB)                                                                          \
+  do {                                                                                               \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
+    __builtin_amdgcn_s_setprio(1);                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                    \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
+      acc[4 * (QI) + i][2 * (QJ) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                     \
+          FB[ks * 2 + j], fa[ks * 4 + i], acc[4 * (QI) + i][2 * (QJ) + j], 0, 0, 0);                 \
+    __builtin_amdgcn_s_setprio(0);                                                                   \
+  } while (0)
+  constexpr int NST = (EPI == EPI_BIAS_GELU ? 2 : 1) * (TM * 16 * TN * 2 / 64);
+  auto wait_vm = [&](int n) {   // at most the n youngest vector-memory instructions of this wave stay outstanding
+    switch (n >> 1) {
+#define CZC_W(N) case N / 2: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+      CZC_W(2) CZC_W(4) CZC_W(8) CZC_W(10) CZC_W(12) CZC_W(16) CZC_W(18) CZC_W(20) CZC_W(32) CZC_W(34) CZC_W(36)
+#undef CZC_W
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+  };
+  if (nt > 0) {
+    // tile 0 whole (unless the previous epilogue requested it), then what "tile -1" would have issued for tile 1
+    if (!primed) { sh(0, 0, 0); sh(0, 0, 1); sh(1, 0, 0); sh(1, 0, 1); }
+    else CZC_BAR();   // the previous epilogue staged through the second buffer: every wave has read its part back
+    int young = primed ? NST : 0;
+    if (nt > 1) { sh(1, 1, 0); young += 2; if (grp == 1) { sh(0, 1, 0); young += 2; } }
+    wait_vm(young);
+    CZC_BAR();
+    if (grp == 1) CZC_BAR();   // G1 runs one barrier behind
+    // STEADY: tiles t+1 and t+2 are full interior tiles: unconditional fast staging and constant wait counts
+#define CZC_PP_TILE(STEADY)                                                                          \
+    {                                                                                                \
+      auto st_ = [&](int opnd, int tt, int h) { if (STEADY) stage_half_fast(opnd, tt, h); else sh(opnd, tt, h); }; \
+      /* ---- Q0 */                                                                                  \
+      load_a(t, 0); load_b(fbl, t, 0);                                                               \
+      if (grp == 0) st_(0, t + 1, 0); else st_(0, t + 1, 1);                                         \
+      CZC_BAR();                                                                                     \
+      CZC_QUAD(0, 0, fbl);                                                                           \
+      CZC_BAR();                                                                                     \
+      /* ---- Q1 */                                                                                  \
+      load_b(fbh, t, 1);                                                                             \
+      if (grp == 0) st_(0, t + 1, 1); else st_(1, t + 1, 1);                                         \
+      CZC_BAR();                                                                                     \
+      CZC_QUAD(0, 1, fbh);                                                                           \
+      CZC_BAR();                                                                                     \
+      /* ---- Q2 */                                                                                  \
+      load_a(t, 1);                                                                                  \
+      if (grp == 0) st_(1, t + 1, 1); else st_(1, t + 2, 0);                                         \
+      CZC_BAR();                                                                                     \
+      CZC_QUAD(1, 1, fbh);                                                                           \
+      CZC_BAR();                                                                                     \
+      /* ---- Q3 */                                                                                  \
+      if (grp == 0) st_(1, t + 2, 0); else st_(0, t + 2, 0);                                         \
+      if (grp == 1) { if (STEADY) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else wait_vm(t + 2 < nt ? 4 : 0); } \
+      CZC_BAR();                                                                                     \
+      CZC_QUAD(1, 0, fbl);                                                                           \
+      if (grp == 0) { if (STEADY) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else wait_vm(t + 2 < nt ? 2 : 0); } \
+      CZC_BAR();                                                                                     \
+    }
+    int t = 0;
+    for (; t + 2 < pntf; ++t) CZC_PP_TILE(true)
+    for (; t < nt; ++t) CZC_PP_TILE(false)
+#undef CZC_PP_TILE
+    if (grp == 0) CZC_BAR();
+  }
+#undef CZC_QUAD
+#undef CZC_BAR
+  } else {
   if (nt > 0) {
     // counted wait when primed: the epilogue's stores were issued after that DMA and need not have been acknowledged
     constexpr int NST = (EPI == EPI_BIAS_GELU ? 2 : 1) * (TM * 16 * TN * 2 / 64);
@@ -379,6 +572,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
 #undef CZC_KTILE
 #undef CZC_INTERLEAVE
 #undef CZC_MFMA_HALF
+  }   // !PP
 
   // ---------------- epilogue ----------------
   // acc[i][j][r] = C[row0 + wm*128 + 16i + (lane&15)][col0 + wn*64 + 16j + 4(lane>>4) + r]
@@ -601,12 +795,13 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
 typedef Cfg<2, 4, 8> CfgBig;
 typedef Cfg<2, 2, 4> CfgSmall;
 static int g_tile_override = 0;  // 0 = heuristic, 1 = 256x256, 2 = 128x128
-static bool g_one_wg_per_tile = false;  // tuning knob: switch the persistent tile loop off
+static bool g_one_wg_per_tile = false;
+static int g_pingpong = 0;             // 0 = built-in choice; tuning knob czc_gemm_set_tile: +32 = always, +64 = never  // tuning knob: switch the persistent tile loop off
 
-template <int AL, int BL, int EPI, class CF>
+template <int AL, int BL, int EPI, class CF, bool PP = false>
 static int launch_cfg(GemmArgs a, int splits, hipStream_t st) {
   static bool attr_done = false;
-  auto kern = gemm_kernel<AL, BL, EPI, CF>;
+  auto kern = gemm_kernel<AL, BL, EPI, CF, PP>;
   if (!attr_done) {
     CZC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS));
     attr_done = true;
@@ -643,6 +838,11 @@ static int launch(const GemmArgs& a, int splits, hipStream_t st) {
   if (EPI == EPI_LSE || EPI == EPI_SOFTGRAD || a.colsum) cfg = 1;  // partial-sum rows are laid out for 256-row tiles
   if (cfg == 0) cfg = (ceil_div(a.M, 256) * ceil_div(a.N, 256) * splits < 128 && !a.colsum) ? 2 : 1;
   if (cfg == 2) return launch_cfg<AL, BL, EPI, CfgSmall>(a, splits, st);
+  // the ping-pong K-loop (see the kernel) where it measured faster than the plain one in interleaved A/B runs:
+  // K-major x K-major products with a long K or a wide N (FFN-up / FFN-down / QKV forward: -1..-5 %); it loses on
+  // the transposing-read kernels (their LOAD slots are twice as long) and on the 768 x 768 projections
+  const bool pp_auto = (AL == 0 && BL == 0 && splits == 1 && (a.K >= 1536 || a.N >= 2304));
+  if (g_pingpong == 1 || (g_pingpong == 0 && pp_auto)) return launch_cfg<AL, BL, EPI, CfgBig, true>(a, splits, st);
   return launch_cfg<AL, BL, EPI, CfgBig>(a, splits, st);
 }
 
@@ -746,10 +946,12 @@ extern "C" int czc_gemm_bf16(int a_layout, int b_layout, int epilogue, int M, in
 }
 
 extern "C" int czc_gemm_set_tile(int cfg) {
-  CZC_REQUIRE((cfg & ~16) >= 0 && (cfg & ~16) <= 2,
-              "czc_gemm_set_tile: cfg=%d (0 default, 1 = 256x256, 2 = 128x128; +16 = one workgroup per tile)", cfg);
-  g_tile_override = cfg & ~16;
+  CZC_REQUIRE((cfg & ~112) >= 0 && (cfg & ~112) <= 2,
+              "czc_gemm_set_tile: cfg=%d (0 default, 1 = 256x256, 2 = 128x128; +16 = one workgroup per tile; "
+              "+32 / +64 = ping-pong K-loop always / never)", cfg);
+  g_tile_override = cfg & ~112;
   g_one_wg_per_tile = (cfg & 16) != 0;
+  g_pingpong = (cfg & 32) ? 1 : ((cfg & 64) ? 2 : 0);
   return CZC_OK;
 }
 

@@ -192,7 +192,8 @@ int czc_gemm_bf16(int a_layout, int b_layout, int epilogue, int M, int N, int K,
 
 /* Tile configuration used by every later GEMM launch that does not choose one itself:
  * 0 = built-in choice, 1 = 256x256 tile (8 waves, 1 workgroup/CU), 2 = 128x128 (4 waves, 2 workgroups/CU);
- * + 16 = one workgroup per output tile instead of workgroups that walk over several tiles (tuning A/B) */
+ * + 16 = one workgroup per output tile instead of workgroups that walk over several tiles (tuning A/B);
+ * + 32 / + 64 = the ping-pong K-loop always / never (default: chosen per shape) */
 int czc_gemm_set_tile(int cfg);
 /* Timing probe (bench only): records hipEvents on the launch stream around every czc GEMM launch whose
  * (layouts, epilogue, M, N, K) match, up to max_samples launches; max_samples <= 0 disarms.

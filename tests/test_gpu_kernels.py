@@ -304,14 +304,15 @@ def test_gemm_workgroups_walking_over_tiles(ops, al, bl):
     lib = L.load()
     for epi, kw in cases:
         outs = []
-        for cfg in (1, 17):   # 256x256 tiles: persistent, then one workgroup per tile
+        for cfg in (1, 17, 33, 65 + 16):   # 256x256 tiles: persistent, one workgroup per tile, ping-pong K-loop, plain per-tile
             L.check(lib.czc_gemm_set_tile(cfg))
             try:
                 o = ops.gemm(A, Bm, a_layout=al, b_layout=bl, M=M, N=N, K=K, epilogue=epi, **kw)
             finally:
                 L.check(lib.czc_gemm_set_tile(0))
             outs.append(o[1] if isinstance(o, tuple) else o)
-        assert torch.equal(outs[0], outs[1]), (epi, (outs[0].float() - outs[1].float()).abs().max())
+        for o in outs[1:]:
+            assert torch.equal(outs[0], o), (epi, (outs[0].float() - o.float()).abs().max())
         if epi == "store":
             report("walk store", outs[0], acc, 0.02 * math.sqrt(K) * 0.25 + 1e-2, 8e-3)
         elif epi == "bias":

@@ -26,6 +26,8 @@ cases = [
     ("dWqkv [2304,768] splitk 9", lambda: ops.gemm(Y3, X, a_layout=1, b_layout=1, epilogue="f32", M=2304, N=768, K=M, splitk=9), 2 * M * 768 * 2304),
 ]
 variants = [("tile256", 1, 0), ("tile128", 2, 0)]
+if len(sys.argv) > 1 and sys.argv[1] == "pp":
+    variants = [("plain", 65, 0), ("pingpong", 33, 0), ("auto", 1, 0)]
 if len(sys.argv) > 1 and sys.argv[1] == "persist":
     variants = [("persist", 1, 0), ("per-tile", 17, 0)]
 if len(sys.argv) > 1 and sys.argv[1] == "tiles":
