@@ -6,6 +6,9 @@
 // multiplied; one barrier per K-tile.  LDS: 2 buffers x (A 32 KiB + B 32 KiB) = 128 KiB.
 // For the bf16 epilogues a workgroup walks over several output tiles (one workgroup per CU): the
 // epilogue stages through the second buffer while the next tile's first K-tile lands in the first.
+// Two K-loops share everything else: the plain one (software-pipelined fragment reads, one barrier per
+// K-tile) and, for the K-major forward products with long K or wide N, the ping-pong one (PP = true:
+// two wave groups one barrier apart, quadrant phases, half-tile LDS refills; described at its top).
 //
 // Each operand may be stored with the reduction index contiguous ("K-major": X[M][K], W[N][K]) or
 // with the free index contiguous ("MN-major": the operand of the weight-gradient and input-
