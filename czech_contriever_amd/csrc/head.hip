@@ -40,16 +40,21 @@ __global__ __launch_bounds__(256) void head_final_kernel(const float* __restrict
                                                          const float* __restrict__ lpos, float invT, float ls,
                                                          float* __restrict__ lse_out, float* __restrict__ rowloss,
                                                          float* __restrict__ rowok) {
-  const int b = blockIdx.x * 256 + threadIdx.x;
+  // one wave per batch row: the lanes split the column tiles (a thread per row walked 2 x 513 dependent loads)
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (b >= B) return;
   const size_t pl = (size_t)tiles * B;
   float mx = -1e30f;
-  for (int t = 0; t < tiles; ++t) mx = fmaxf(mx, part[(size_t)t * B + b]);
+  for (int t = lane; t < tiles; t += 64) mx = fmaxf(mx, part[(size_t)t * B + b]);
+  mx = wave_max(mx);
   float se = 0.f, sm = 0.f;
-  for (int t = 0; t < tiles; ++t) {
+  for (int t = lane; t < tiles; t += 64) {
     se += part[pl + (size_t)t * B + b] * __expf(part[(size_t)t * B + b] - mx);
     sm += part[2 * pl + (size_t)t * B + b];
   }
+  se = wave_sum(se);
+  sm = wave_sum(sm);
+  if (lane != 0) return;
   const float z0 = lpos[b] * invT;
   const float M = fmaxf(mx, z0);
   const float tot = se * __expf(mx - M) + __expf(z0 - M);
@@ -77,21 +82,26 @@ __global__ __launch_bounds__(256) void head_mean_kernel(const float* __restrict_
 
 // out[0] += mean_c std_b(x[:, c])  (unbiased, torch.std(x, dim=0).mean())
 __global__ __launch_bounds__(256) void colstd_kernel(const float* __restrict__ x, int B, int C, float* out) {
-  __shared__ float red[4];
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  float sd = 0.f;
-  if (c < C) {
-    float m = 0.f;
-    for (int b = 0; b < B; ++b) m += x[(size_t)b * C + c];
-    m /= (float)B;
-    float v = 0.f;
-    for (int b = 0; b < B; ++b) { const float d = x[(size_t)b * C + c] - m; v += d * d; }
-    sd = sqrtf(v / (float)(B - 1));
-  }
-  sd = wave_sum(sd);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sd;
+  // 64 columns per workgroup, the four waves split the rows; two passes (mean, then squared deviations) as torch.std
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float m = 0.f;
+  if (c < C) for (int b = w; b < B; b += 4) m += x[(size_t)b * C + c];
+  red[w][lane] = m;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1] + red[2] + red[3]) / (float)C);
+  m = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)B;
+  __syncthreads();
+  float v = 0.f;
+  if (c < C) for (int b = w; b < B; b += 4) { const float d = x[(size_t)b * C + c] - m; v += d * d; }
+  red[w][lane] = v;
+  __syncthreads();
+  if (w == 0) {
+    v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    float sd = (c < C) ? sqrtf(v / (float)(B - 1)) : 0.f;
+    sd = wave_sum(sd);
+    if (lane == 0) atomicAdd(out, sd / (float)C);
+  }
 }
 
 // dq = scale * (sum_z slab[z] + coef0[b] * k)
@@ -213,11 +223,11 @@ extern "C" int czc_infonce_forward(const float* q, const float* k, const uint16_
   a.A = qb; a.B = queue_bf16; a.M = batch; a.N = queue_size; a.K = dim;
   a.lda = dim; a.ldb = dim; a.ldc = queue_size; a.C = part; a.part = part; a.alpha = invT;
   if (int rc = gemm_dispatch(0, 0, EPI_LSE, a, 1, st)) return rc;
-  hipLaunchKernelGGL(head_final_kernel, dim3(ceil_div(batch, 256)), dim3(256), 0, st, part, w.tiles, batch, queue_size,
+  hipLaunchKernelGGL(head_final_kernel, dim3(ceil_div(batch, 4)), dim3(256), 0, st, part, w.tiles, batch, queue_size,
                      lpos, invT, label_smoothing, lse_out, rowloss, rowok);
   hipLaunchKernelGGL(head_mean_kernel, dim3(1), dim3(256), 0, st, rowloss, rowok, batch, stats_out);
-  hipLaunchKernelGGL(colstd_kernel, dim3(ceil_div(dim, 256)), dim3(256), 0, st, q, batch, dim, stats_out + 2);
-  hipLaunchKernelGGL(colstd_kernel, dim3(ceil_div(dim, 256)), dim3(256), 0, st, k, batch, dim, stats_out + 3);
+  hipLaunchKernelGGL(colstd_kernel, dim3(ceil_div(dim, 64)), dim3(256), 0, st, q, batch, dim, stats_out + 2);
+  hipLaunchKernelGGL(colstd_kernel, dim3(ceil_div(dim, 64)), dim3(256), 0, st, k, batch, dim, stats_out + 3);
   CZC_LAUNCH_CHECK();
   return CZC_OK;
 }

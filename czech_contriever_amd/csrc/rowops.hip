@@ -407,12 +407,24 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict_
   int cnt = 0;
   const bf16_t* xb = x + (size_t)b * S * H;
   if (pooling == CZC_POOL_AVERAGE) {
-    for (int s = 0; s < S; ++s) {
-      if (m_s[s]) {
-        ++cnt;
-        if (c < H) sum += ld_bf4(xb + (size_t)s * H + c);
+    // eight rows in flight per thread (a load under `if (mask)` was waited for before the next was issued: one memory
+    // round trip per token); masked rows are loaded and multiplied by 0
+    f32x4 part[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) part[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int cc = (c < H) ? c : 0;
+    for (int s = 0; s < S; s += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ld_bf4(xb + (size_t)min(s + u, S - 1) * H + cc);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool on = (s + u < S) && m_s[min(s + u, S - 1)];
+        cnt += on ? 1 : 0;
+        part[u] += v[u] * (on ? 1.0f : 0.0f);
       }
     }
+    sum = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
     // torch: sum / count  (count == 0 gives nan/inf exactly as the reference's 0/0 would)
     const float inv = 1.0f / (float)cnt;
     sum = sum * inv;
