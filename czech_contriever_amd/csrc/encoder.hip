@@ -153,6 +153,43 @@ static int gemm(int al, int bl, int epi, int M, int N, int K, const void* A, int
 }
 #define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
+// one 64 x 64 tile of one weight matrix per workgroup: rows of `src` in (16 B per lane), transposed through LDS,
+// rows of `dst` out; block id -> (layer, matrix, tile) from the shape alone
+__global__ __launch_bounds__(256) void transpose_matrices_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                                 int H, int I, int64_t layer_stride, int64_t o_qkv,
+                                                                 int64_t o_o, int64_t o_1, int64_t o_2) {
+  __shared__ bf16_t t[64][66];
+  const int th = H / 64, ti = I / 64;
+  const int per_layer = 3 * th * th + th * th + 2 * ti * th;
+  int bid = blockIdx.x;
+  const int layer = bid / per_layer;
+  bid -= layer * per_layer;
+  int rows, cols; int64_t off;
+  if (bid < 3 * th * th)          { rows = 3 * H; cols = H; off = o_qkv; }
+  else if ((bid -= 3 * th * th) < th * th) { rows = H; cols = H; off = o_o; }
+  else if ((bid -= th * th) < ti * th)     { rows = I; cols = H; off = o_1; }
+  else { bid -= ti * th;            rows = H; cols = I; off = o_2; }
+  const int tc = cols / 64, tr = bid / tc, tcn = bid % tc;
+  const bf16_t* s0 = src + layer * layer_stride + off + (size_t)(tr * 64) * cols + tcn * 64;
+  bf16_t* d0 = dst + layer * layer_stride + off + (size_t)(tcn * 64) * rows + tr * 64;
+  const int r = threadIdx.x >> 3, c8 = (threadIdx.x & 7) * 8;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint4 v = *(const uint4*)(s0 + (size_t)(r + 32 * h) * cols + c8);
+    const bf16_t* e = (const bf16_t*)&v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[r + 32 * h][c8 + j] = e[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    bf16_t o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = t[c8 + j][r + 32 * h];
+    *(uint4*)(d0 + (size_t)(r + 32 * h) * rows + c8) = *(const uint4*)o;
+  }
+}
+
 }  // namespace czc
 
 using namespace czc;
@@ -163,6 +200,22 @@ extern "C" int64_t czc_param_offset(const czc_bert_shape* s, int kind, int layer
   if (!s || kind < 0 || kind >= CZC_P_KINDS || layer < 0 || layer >= s->num_layers) return -1;
   return param_off(param_layout(s), kind, kind >= CZC_P_WORD ? 0 : layer);
 }
+extern "C" int czc_transpose_matrices(const czc_bert_shape* s, const uint16_t* src, uint16_t* dst, czc_stream_t stream) {
+  RC(shape_check("czc_transpose_matrices", s));
+  CZC_REQUIRE(src && dst && src != dst, "czc_transpose_matrices: null or aliased arguments");
+  CZC_REQUIRE(s->hidden_size % 64 == 0 && s->intermediate_size % 64 == 0,
+              "czc_transpose_matrices: hidden %d / intermediate %d must be multiples of 64", s->hidden_size, s->intermediate_size);
+  const ParamLayout pl = param_layout(s);
+  const int H = s->hidden_size, I = s->intermediate_size, th = H / 64, ti = I / 64;
+  const int per_layer = 3 * th * th + th * th + 2 * ti * th;
+  const int64_t stride = s->num_layers > 1 ? param_off(pl, CZC_P_WQKV, 1) - param_off(pl, CZC_P_WQKV, 0) : 0;
+  const int64_t base = param_off(pl, CZC_P_WQKV, 0);
+  hipLaunchKernelGGL(transpose_matrices_kernel, dim3(per_layer * s->num_layers), dim3(256), 0, (hipStream_t)stream, src, dst, H, I,
+                     stride, base, param_off(pl, CZC_P_WO, 0), param_off(pl, CZC_P_W1, 0), param_off(pl, CZC_P_W2, 0));
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
 extern "C" int64_t czc_encoder_workspace_bytes(const czc_bert_shape* s, int batch, int seq, int save_for_backward) {
   if (!s || batch <= 0 || seq <= 0 || s->num_layers > 64) return -1;
   return enc_layout(s, batch, seq, save_for_backward).total;
@@ -219,7 +272,7 @@ extern "C" int czc_encoder_forward(const czc_bert_shape* s, const float* params_
   return CZC_OK;
 }
 
-extern "C" int czc_encoder_backward(const czc_bert_shape* s, const float* params_f32, const uint16_t* params_bf16,
+extern "C" int czc_encoder_backward(const czc_bert_shape* s, const float* params_f32, const uint16_t* params_bf16, const uint16_t* params_bf16_t,
                                     const int64_t* ids, const uint8_t* mask, int batch, int seq, int pooling,
                                     int normalize, int training, uint32_t seed, void* workspace,
                                     int64_t workspace_bytes, void* scratch, int64_t scratch_bytes, const float* d_emb,
@@ -244,7 +297,15 @@ extern "C" int czc_encoder_backward(const czc_bert_shape* s, const float* params
   const float ph = training ? s->hidden_dropout : 0.f, pa = training ? s->attn_dropout : 0.f;
   const float* P = params_f32;
   const uint16_t* W = params_bf16;
+  const uint16_t* WT = params_bf16_t;   // transposed weight matrices at the same offsets, or null
   float* G = grads_f32;
+#define WTB(kind, l) (WT + param_off(pl, kind, l))
+  // dX = dY . W: with the transposed mirror W^T is [in][out] row-major, a K-major operand (b_layout 0, ld = out)
+  auto dinput = [&](int epi, int Mx, int Nin, int Kout, const void* dY, int ldy, int kind, int l, void* dst, int ldd,
+                    const void* aux, float* colsum) -> int {
+    if (WT) return gemm(0, 0, epi, Mx, Nin, Kout, dY, ldy, WTB(kind, l), Kout, dst, ldd, nullptr, aux, nullptr, 1, st, colsum);
+    return gemm(0, 1, epi, Mx, Nin, Kout, dY, ldy, WB(kind, l), Nin, dst, ldd, nullptr, aux, nullptr, 1, st, colsum);
+  };
 #define GF(kind, l) (G + param_off(pl, kind, l))
 #define SBUF(off) ((uint16_t*)(sc + (off)))
 
@@ -273,19 +334,19 @@ extern "C" int czc_encoder_backward(const czc_bert_shape* s, const float* params
     RC(czc_residual_ln_backward(g0, nullptr, BUF(w.y2), BUF(w.x1), FBUF(w.st2), M, H, PF(CZC_P_LN2W, l), ph, seed,
                                 SITE_H2(l), Z, Y, GF(CZC_P_LN2W, l), GF(CZC_P_LN2B, l), GF(CZC_P_B2, l), part, stream));
     RC(dweight(H, I, Y, H, BUF(w.hact), I, GF(CZC_P_W2, l)));
-    RC(gemm(0, 1, EPI_DGELU, M, I, H, Y, H, WB(CZC_P_W2, l), I, U, I, nullptr, BUF(w.u), nullptr, 1, st, part));
+    RC(dinput(EPI_DGELU, M, I, H, Y, H, CZC_P_W2, l, U, I, BUF(w.u), part));
     RC(czc_reduce_partials(part, ceil_div(M, 256) * 2, I, I, GF(CZC_P_B1, l), stream));
     RC(dweight(I, H, U, I, BUF(w.x1), H, GF(CZC_P_W1, l)));
-    RC(gemm(0, 1, EPI_ADD, M, H, I, U, I, WB(CZC_P_W1, l), H, X1, H, nullptr, Z, nullptr, 1, st));
+    RC(dinput(EPI_ADD, M, H, I, U, I, CZC_P_W1, l, X1, H, Z, nullptr));
     // x1 = LN(drop(y1) + x[l])
     RC(czc_residual_ln_backward(X1, nullptr, BUF(w.y1), BUF(e.x[l]), FBUF(w.st1), M, H, PF(CZC_P_LN1W, l), ph, seed,
                                 SITE_H1(l), Z, Y, GF(CZC_P_LN1W, l), GF(CZC_P_LN1B, l), GF(CZC_P_BO, l), part, stream));
     RC(dweight(H, H, Y, H, BUF(w.ctx), H, GF(CZC_P_WO, l)));
-    RC(gemm(0, 1, EPI_STORE, M, H, H, Y, H, WB(CZC_P_WO, l), H, C, H, nullptr, nullptr, nullptr, 1, st));
+    RC(dinput(EPI_STORE, M, H, H, Y, H, CZC_P_WO, l, C, H, nullptr, nullptr));
     RC(czc_attention_backward(BUF(w.qkv), mask, BUF(w.ctx), C, FBUF(w.lse), batch, seq, nh, pa, seed, SITE_ATTN(l), delta, Q3,
                               GF(CZC_P_BQKV, l), part, stream));
     RC(dweight(3 * H, H, Q3, 3 * H, BUF(e.x[l]), H, GF(CZC_P_WQKV, l)));
-    RC(gemm(0, 1, EPI_ADD, M, H, 3 * H, Q3, 3 * H, WB(CZC_P_WQKV, l), H, g0, H, nullptr, Z, nullptr, 1, st));
+    RC(dinput(EPI_ADD, M, H, 3 * H, Q3, 3 * H, CZC_P_WQKV, l, g0, H, Z, nullptr));
   }
   if (last)
   RC(czc_embed_ln_backward(ids, batch, seq, H, s->vocab_size, PF(CZC_P_WORD, 0), PF(CZC_P_POS, 0), PF(CZC_P_TYPE, 0),

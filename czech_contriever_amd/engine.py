@@ -93,6 +93,9 @@ class FlatBertEncoder(nn.Module):
         self._flat_grad = None
         self._mirror = None
         self._mirror_version = -1
+        self._mirror_epoch = 0
+        self._mirror_t = None
+        self._mirror_t_epoch = -1
         self._ws: Dict[tuple, torch.Tensor] = {}
         self._ws_pool: Dict[tuple, list] = {}
         self._scratch = None
@@ -143,6 +146,7 @@ class FlatBertEncoder(nn.Module):
             if moved:
                 self._flat_grad = None
                 self._mirror = None
+                self._mirror_t = None
                 self._ws.clear()
                 self._ws_pool.clear()
                 self._scratch = None
@@ -186,10 +190,26 @@ class FlatBertEncoder(nn.Module):
         if self._mirror_version != self._flat._version:
             L.check(L.load().czc_cast_bf16(self._flat.data_ptr(), self._mirror.data_ptr(), self._n_mat, L.stream_ptr()))
             self._mirror_version = self._flat._version
+            self._mirror_epoch += 1
         return self._mirror
 
     def mark_mirror_fresh(self):
         self._mirror_version = self._flat._version
+        self._mirror_epoch += 1
+
+    def mirror_t(self):
+        """The matrix region with every weight matrix transposed (czc_transpose_matrices), for the backward's input-
+        gradient products; None when the shape does not tile by 64.  Rebuilt (one launch) whenever the mirror changed."""
+        m = self.mirror()
+        if self.config.hidden_size % 64 or self.config.intermediate_size % 64:
+            return None
+        if self._mirror_t is None or self._mirror_t.device != m.device:
+            self._mirror_t = torch.empty_like(m)
+            self._mirror_t_epoch = -1
+        if self._mirror_t_epoch != self._mirror_epoch:
+            L.check(L.load().czc_transpose_matrices(C.byref(self._shape), m.data_ptr(), self._mirror_t.data_ptr(), L.stream_ptr()))
+            self._mirror_t_epoch = self._mirror_epoch
+        return self._mirror_t
 
     def _workspace(self, B, S, save):
         key = (B, S, int(save))
@@ -290,11 +310,13 @@ class FlatBertEncoder(nn.Module):
         la = self._n_mat // nl                       # matrix-region elements per layer
         d_emb = d_emb.contiguous()
         mirror = self.mirror()
+        mirror_t = self.mirror_t()
+        mt_ptr = mirror_t.data_ptr() if mirror_t is not None else None
         hi = nl
         while hi > 0:
             lo = max(0, hi - step)
             L.check(L.load().czc_encoder_backward(
-                C.byref(self._shape), self._flat.data_ptr(), mirror.data_ptr(), ids.data_ptr(), mask.data_ptr(),
+                C.byref(self._shape), self._flat.data_ptr(), mirror.data_ptr(), mt_ptr, ids.data_ptr(), mask.data_ptr(),
                 B, S, self._pool_code(), int(normalize), int(training), seed, ws.data_ptr(), ws.numel(), sc.data_ptr(),
                 sc.numel(), d_emb.data_ptr(), g.data_ptr(), 0 if fresh else 1, hi, lo, L.stream_ptr()))
             for hook in self._range_hooks:

@@ -36,7 +36,8 @@ SIGNATURES = {
     "czc_encoder_workspace_bytes": (i64, [SP, i32, i32, i32]),
     "czc_encoder_backward_scratch_bytes": (i64, [SP, i32, i32]),
     "czc_encoder_forward": (i32, [SP, vp, vp, vp, vp, i32, i32, i32, i32, i32, u32, i32, vp, i64, vp, vp]),
-    "czc_encoder_backward": (i32, [SP, vp, vp, vp, vp, i32, i32, i32, i32, i32, u32, vp, i64, vp, i64, vp, vp, i32, i32, i32, vp]),
+    "czc_encoder_backward": (i32, [SP, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, u32, vp, i64, vp, i64, vp, vp, i32, i32, i32, vp]),
+    "czc_transpose_matrices": (i32, [SP, vp, vp, vp]),
     "czc_infonce_workspace_bytes": (i64, [i32, i32, i32]),
     "czc_infonce_forward": (i32, [vp, vp, vp, i32, i32, i32, f32, f32, vp, i64, vp, vp, vp]),
     "czc_infonce_backward": (i32, [vp, vp, vp, i32, i32, i32, f32, f32, vp, f32, vp, i64, vp, vp]),
@@ -85,7 +86,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError = a symbol czc.h declares is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.czc_abi_version() != 1:
+    if lib.czc_abi_version() != 2:
         raise RuntimeError("libczc.so ABI version mismatch")
     _lib = lib
     return lib
