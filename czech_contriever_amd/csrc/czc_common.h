@@ -157,6 +157,31 @@ __device__ __forceinline__ GeluParts gelu_parts(float x) {
   return g;
 }
 __device__ __forceinline__ float gelu_f(float x) { return x * gelu_parts(x).cdf; }
+// the same for 8 values, written stage by stage (all exponentials, all reciprocals, all polynomials ...): a
+// transcendental's result may not be used by the very next instructions, and element-at-a-time code made the compiler
+// pad every exp / rcp with s_nops (37 per 8 elements in the GELU epilogues)
+template <bool DERIV>
+__device__ __forceinline__ void gelu8(const float (&x)[8], float (&out)[8]) {
+  float e[8], t[8], p[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(x[i] * x[i] * -0.72134752044448170368f);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t[i] = __builtin_amdgcn_rcpf(fmaf(fabsf(x[i]), 0.3275911f * 0.70710678118654752440f, 1.0f));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) p[i] = fmaf(1.061405429f, t[i], -1.453152027f);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) p[i] = fmaf(p[i], t[i], 1.421413741f);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) p[i] = fmaf(p[i], t[i], -0.284496736f);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) p[i] = fmaf(p[i], t[i], 0.254829592f);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float h = 0.5f * p[i] * t[i] * e[i];            // 0.5 * erfc(|x| / sqrt 2)
+    const float cdf = x[i] >= 0.f ? 1.0f - h : h;
+    out[i] = DERIV ? fmaf(x[i], 0.39894228040143267794f * e[i], cdf) : x[i] * cdf;
+  }
+}
 __device__ __forceinline__ float dgelu_f(float x) {
   const GeluParts g = gelu_parts(x);
   return g.cdf + x * g.pdf;

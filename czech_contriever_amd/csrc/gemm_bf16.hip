@@ -747,23 +747,26 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
       const int m = row0 + wm * TM * 16 + (it * 64 + lane) / NCH;
       const unsigned off = seg_off(it);
       const u32x4 v = sv[itp];
-      if (EPI == EPI_BIAS_GELU) {
-        __builtin_amdgcn_raw_buffer_store_b128(v, rc, off, 0, 0);
+      if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU1) {
+        if (EPI == EPI_BIAS_GELU) __builtin_amdgcn_raw_buffer_store_b128(v, rc, off, 0, 0);
+        float xin[8], gl[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { xin[2 * e] = bflo(v[e]); xin[2 * e + 1] = bfhi(v[e]); }
+        gelu8<false>(xin, gl);
         u32x4 g;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) g[e] = pack2bf(gelu_f(bflo(v[e])), gelu_f(bfhi(v[e])));
-        __builtin_amdgcn_raw_buffer_store_b128(g, rc2, off, 0, 0);
-      } else if (EPI == EPI_BIAS_GELU1) {
-        u32x4 g;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) g[e] = pack2bf(gelu_f(bflo(v[e])), gelu_f(bfhi(v[e])));
-        __builtin_amdgcn_raw_buffer_store_b128(g, rc, off, 0, 0);
+        for (int e = 0; e < 4; ++e) g[e] = pack2bf(gl[2 * e], gl[2 * e + 1]);
+        __builtin_amdgcn_raw_buffer_store_b128(g, EPI == EPI_BIAS_GELU ? rc2 : rc, off, 0, 0);
       } else if (EPI == EPI_DGELU) {
         const u32x4 u = au[it];
+        float xin[8], dg[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { xin[2 * e] = bflo(u[e]); xin[2 * e + 1] = bfhi(u[e]); }
+        gelu8<true>(xin, dg);
         u32x4 g;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float lo = bflo(v[e]) * dgelu_f(bflo(u[e])), hi = bfhi(v[e]) * dgelu_f(bfhi(u[e]));
+          const float lo = bflo(v[e]) * dg[2 * e], hi = bfhi(v[e]) * dg[2 * e + 1];
           g[e] = pack2bf(lo, hi);
           if (m < a.M) { csum[2 * e] += lo; csum[2 * e + 1] += hi; }
         }
