@@ -83,6 +83,35 @@ def test_train_cli_inbatch_mode(tmp_path, monkeypatch):
     assert ck["optimizer"]["state"][0]["step"] == 3
 
 
+def test_train_cli_on_jsonl_corpus(tmp_path, monkeypatch):
+    """--train_data: jsonl -> local WordPiece vocab -> src.data (Dataset, random crops, Collator) -> DataLoader -> the
+    GPU step, with queries and keys padded to different widths."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import random
+    import train
+    mdir = _cfg_dir(tmp_path)
+    words = [f"w{i}" for i in range(507)]
+    with open(os.path.join(mdir, "vocab.txt"), "w") as f:
+        f.write("\n".join(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + words) + "\n")
+    rng = random.Random(0)
+    corpus = tmp_path / "corpus.jsonl"
+    with open(corpus, "w") as f:
+        for _ in range(40):
+            f.write(json.dumps({"text": " ".join(rng.choice(words) for _ in range(rng.randint(12, 60)))}) + "\n")
+    out = str(tmp_path / "run_corpus")
+    args = ["--retriever_model_id", mdir, "--random_init", "--output_dir", out, "--save_dir", out, "--train_data", str(corpus),
+            "--chunk_length", "32", "--per_gpu_batch_size", "8", "--target_batch_size", "8", "--queue_size", "64",
+            "--projection_size", "128", "--temperature", "0.05", "--momentum", "0.99", "--lr", "1e-3", "--warmup_steps", "1",
+            "--total_steps", "7", "--save_freq", "7", "--log_freq", "1", "--norm_query", "--norm_doc", "--num_workers", "0"]
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    train.main(args)   # 40 documents / batch 8 = 5 batches per epoch: 7 steps cross an epoch boundary
+    ck = torch.load(os.path.join(out, "checkpoint", "step-7", "checkpoint.pth"), map_location="cpu", weights_only=False)
+    assert ck["step"] == 7 and int(ck["model"]["queue_ptr"]) == (7 * 8) % 64
+    assert torch.isfinite(ck["model"]["encoder_q.encoder.layer.0.output.dense.weight"]).all()
+
+
 def test_weight_decay_from_init_matches_oracle(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")

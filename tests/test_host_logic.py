@@ -65,16 +65,16 @@ def test_no_cpu_fallback():
 
 
 def test_scheduler_and_data_contract():
-    from src import utils, data_min
+    from src import utils, data
     import random
     p = torch.nn.Parameter(torch.zeros(4))
     o = torch.optim.SGD([p], lr=1.0)
     s = utils.WarmupLinearScheduler(o, warmup=3, total=10, ratio=0.1)
     lam = [s.lr_lambda(i) for i in range(12)]
     assert lam[0] == 0.0 and abs(lam[3] - 1.0) < 1e-12 and abs(lam[10] - 0.1) < 1e-12 and lam[11] < lam[10]
-    rng = random.Random(0)
-    c = data_min.crop(list(range(100)), 0.1, 0.5, rng)
+    random.seed(0)
+    c = data.randomcrop(torch.arange(100), 0.1, 0.5).tolist()
     assert 10 <= len(c) <= 50 and c == list(range(c[0], c[0] + len(c)))
-    ids, mask = data_min.pad_batch([[5, 6, 7], [9]])
+    ids, mask = data.build_mask([torch.tensor([5, 6, 7]), torch.tensor([9])])
     assert ids.tolist() == [[5, 6, 7], [9, 0, 0]] and mask.tolist() == [[True, True, True], [True, False, False]]
     assert ids.dtype == torch.int64 and mask.dtype == torch.bool

@@ -13,8 +13,9 @@ libczc.so path.  Differences from the file as committed upstream (SURVEY.md "fiv
     over RCCL, no per-forward 403 MB queue broadcast)
   * the batch is moved with non_blocking copies; stats stay on the device until log_freq
   * per-parameter grad norms (197 host syncs) are replaced by ONE squared-norm reduction
-  * data: `--train_data` jsonl files are read by src/data_min.py (tokenise, two random crops, [CLS]/[SEP],
-    pad id 0); with no `--train_data` the loop runs on synthetic token ids (seed 1234 + 1000*rank + step).
+  * data: `--train_data` goes through src/data.py (the reference's load_data / Dataset / Collator surface and
+    sampling order) and a torch DataLoader; with no `--train_data` the loop runs on synthetic token ids
+    (seed 1234 + 1000*rank + step).
   * BEIR / validation-set evaluation (eval_model, eval_loss) are outside the hot path and not built.
 """
 import logging
@@ -55,11 +56,36 @@ class SyntheticPairs:
         return {"q_tokens": q, "q_mask": m, "k_tokens": k, "k_mask": m.clone()}, None
 
 
+class _Epochs:
+    """The reference's epoch loop (train.py:248-256): a DataLoader over src.data's dataset, reshuffled per epoch."""
+
+    def __init__(self, loader, sampler):
+        self.loader, self.sampler, self.epoch = loader, sampler, 0
+
+    def __iter__(self):
+        while True:
+            self.epoch += 1
+            if hasattr(self.sampler, "set_epoch"):
+                self.sampler.set_epoch(self.epoch)
+            for item in self.loader:
+                yield item
+
+
 def make_batches(opt, model, rank, world):
     core = model.module if hasattr(model, "module") else model
     if opt.train_data:
-        from src import data_min
-        return data_min.loader(opt, core.tokenizer, rank, world)
+        # reference train.py:183-206: load_data -> RandomSampler / DistributedSampler -> DataLoader(collate_fn=Collator)
+        from src import data
+        if core.tokenizer is None:
+            raise RuntimeError("--train_data needs a local tokenizer (vocab.txt next to the model's config.json)")
+        train_dataset, _ = data.load_data(opt, core.tokenizer, is_main=dist_utils.is_main())
+        if world > 1:
+            sampler = torch.utils.data.distributed.DistributedSampler(train_dataset, num_replicas=world, rank=rank, shuffle=True)
+        else:
+            sampler = torch.utils.data.RandomSampler(train_dataset)
+        loader = torch.utils.data.DataLoader(train_dataset, sampler=sampler, batch_size=opt.per_gpu_batch_size, drop_last=True,
+                                             num_workers=getattr(opt, "num_workers", 0), collate_fn=data.Collator(opt=opt))
+        return _Epochs(loader, sampler)
     return SyntheticPairs(opt, rank, core.get_encoder().config.vocab_size)
 
 
