@@ -152,6 +152,29 @@ def test_encoder_odd_shapes_vs_oracle(gpu, B, S, lengths):
         assert float(torch.nn.functional.cosine_similarity(got, want, dim=0)) >= 1 - 3e-3
 
 
+@pytest.mark.parametrize("shape_kw", [
+    dict(vocab_size=1024, hidden_size=1024, num_hidden_layers=2, num_attention_heads=16, intermediate_size=4096, max_position_embeddings=128),
+    dict(vocab_size=1024, hidden_size=320, num_hidden_layers=2, num_attention_heads=5, intermediate_size=1280, max_position_embeddings=128),
+])
+def test_encoder_other_widths_vs_oracle(gpu, shape_kw):
+    """bert-large width (1024: four float4 chunks per lane in the row kernels) and a width that is not a multiple of the
+    256-wide GEMM tiles (320 = 5 heads; intermediate 1280): forward and every gradient against the oracle."""
+    enc, P, cfg_o = make_encoder(shape_kw, 51, "average", gpu)
+    enc.eval()
+    B, S = 6, 96
+    ids, mask = ragged_batch(B, S, 52, 1024, [96, 40, 7, 96, 65, 1])
+    Pg = {n: v.clone().requires_grad_(True) for n, v in P.items()}
+    ref = O.encoder_forward(Pg, ids, mask, cfg_o, "average", True)
+    emb = enc(input_ids=ids.to(gpu), attention_mask=mask.to(gpu), normalize=True)
+    assert float(cos_rows(emb.detach().cpu(), ref.detach()).min()) >= 1 - 1e-3
+    cot = O.det_uniform((B, cfg_o.hidden_size), 53)
+    (ref * cot).sum().backward()
+    (emb * cot.to(gpu)).sum().backward()
+    got = torch.cat([p.grad.reshape(-1) for p in enc.parameters()]).cpu().double()
+    want = torch.cat([Pg[n].grad.reshape(-1) for n, _ in O.param_names(cfg_o)]).double()
+    assert float(torch.nn.functional.cosine_similarity(got, want, dim=0)) >= 1 - 3e-3
+
+
 def _moco_opt(model_dir, **kw):
     d = dict(queue_size=64, momentum=0.99, temperature=0.05, label_smoothing=0.0, norm_doc=False, norm_query=False,
              moco_train_mode_encoder_k=False, weight_decay=0.01, weight_decay_from_init=False,
