@@ -88,9 +88,9 @@ __device__ __forceinline__ bf16x8 ld_frag_global(const bf16_t* p) {
 __device__ __forceinline__ void keep4(uint32_t key, uint32_t e, uint32_t thr, float inv_keep, float (&z)[4]) {
   const czc_quad q = czc_rng_quad(key, e >> 2);
   z[0] = ((q.lo & 0xffffu) >= thr) ? inv_keep : 0.f;
-  z[1] = ((q.lo >> 16) >= thr) ? inv_keep : 0.f;
+  z[1] = (q.lo >= (thr << 16)) ? inv_keep : 0.f;
   z[2] = ((q.hi & 0xffffu) >= thr) ? inv_keep : 0.f;
-  z[3] = ((q.hi >> 16) >= thr) ? inv_keep : 0.f;
+  z[3] = (q.hi >= (thr << 16)) ? inv_keep : 0.f;
 }
 
 struct AttnArgs {
@@ -216,9 +216,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
           for (int g = 0; g < 4; ++g) {
             const czc_quad qd = czc_rng_quad(rkey, (erow + (uint32_t)(kb0 + 32 * tt + 8 * g + 4 * h)) >> 2);
             s[4 * g + 0] = ((qd.lo & 0xffffu) >= a.thr) ? s[4 * g + 0] : 0.f;
-            s[4 * g + 1] = ((qd.lo >> 16) >= a.thr) ? s[4 * g + 1] : 0.f;
+            s[4 * g + 1] = (qd.lo >= (a.thr << 16)) ? s[4 * g + 1] : 0.f;
             s[4 * g + 2] = ((qd.hi & 0xffffu) >= a.thr) ? s[4 * g + 2] : 0.f;
-            s[4 * g + 3] = ((qd.hi >> 16) >= a.thr) ? s[4 * g + 3] : 0.f;
+            s[4 * g + 3] = (qd.hi >= (a.thr << 16)) ? s[4 * g + 3] : 0.f;
           }
         }
 #pragma unroll
@@ -364,9 +364,9 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_res_kernel(const AttnArgs a) 
       for (int g = 0; g < 4; ++g) {
         const czc_quad qd = czc_rng_quad(rkey, (erow + (uint32_t)(k0 + 8 * g + 4 * h)) >> 2);
         s[4 * g + 0] = ((qd.lo & 0xffffu) >= a.thr) ? s[4 * g + 0] : 0.f;
-        s[4 * g + 1] = ((qd.lo >> 16) >= a.thr) ? s[4 * g + 1] : 0.f;
+        s[4 * g + 1] = (qd.lo >= (a.thr << 16)) ? s[4 * g + 1] : 0.f;
         s[4 * g + 2] = ((qd.hi & 0xffffu) >= a.thr) ? s[4 * g + 2] : 0.f;
-        s[4 * g + 3] = ((qd.hi >> 16) >= a.thr) ? s[4 * g + 3] : 0.f;
+        s[4 * g + 3] = (qd.hi >= (a.thr << 16)) ? s[4 * g + 3] : 0.f;
       }
     }
 #pragma unroll

@@ -40,9 +40,9 @@ __device__ __forceinline__ f32x4 drop_scale4(uint32_t seed, uint32_t site, uint3
   const czc_quad q = czc_rng_quad(czc_rng_key(seed, site), e >> 2);
   f32x4 s;
   s[0] = ((q.lo & 0xffffu) >= thr) ? inv_keep : 0.f;
-  s[1] = ((q.lo >> 16) >= thr) ? inv_keep : 0.f;
+  s[1] = (q.lo >= (thr << 16)) ? inv_keep : 0.f;
   s[2] = ((q.hi & 0xffffu) >= thr) ? inv_keep : 0.f;
-  s[3] = ((q.hi >> 16) >= thr) ? inv_keep : 0.f;
+  s[3] = (q.hi >= (thr << 16)) ? inv_keep : 0.f;
   return s;
 }
 
@@ -50,8 +50,8 @@ __device__ __forceinline__ f32x4 drop_scale4(uint32_t seed, uint32_t site, uint3
 // carries a row's dropout decisions from its first to its second phase in one register instead of twelve
 __device__ __forceinline__ uint32_t drop_bits4(uint32_t seed, uint32_t site, uint32_t e, uint32_t thr) {
   const czc_quad q = czc_rng_quad(czc_rng_key(seed, site), e >> 2);
-  return ((q.lo & 0xffffu) >= thr ? 1u : 0u) | ((q.lo >> 16) >= thr ? 2u : 0u) |
-         ((q.hi & 0xffffu) >= thr ? 4u : 0u) | ((q.hi >> 16) >= thr ? 8u : 0u);
+  return ((q.lo & 0xffffu) >= thr ? 1u : 0u) | (q.lo >= (thr << 16) ? 2u : 0u) |
+         ((q.hi & 0xffffu) >= thr ? 4u : 0u) | (q.hi >= (thr << 16) ? 8u : 0u);
 }
 __device__ __forceinline__ f32x4 bits_scale4(uint32_t bits, float inv_keep) {
   return (f32x4){(bits & 1u) ? inv_keep : 0.f, (bits & 2u) ? inv_keep : 0.f, (bits & 4u) ? inv_keep : 0.f,
