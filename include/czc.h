@@ -271,6 +271,26 @@ int czc_pool_backward(const float* d_emb, const float* raw, const uint8_t* mask,
 /* fill keep[i] (uint8) for element i of a dropout site: lets tests hand the oracle the same mask */
 int czc_dropout_mask(uint32_t seed, uint32_t site, float p, int64_t n, uint8_t* keep, czc_stream_t stream);
 
+/* ---- flat inner-product passage index: exact top-k search ---------------------------------------------------
+ * Replaces faiss.IndexFlatIP.search as called by Indexer.search_knn, reference src/index.py:35-47 (driven from
+ * passage_retrieval.py:184-186).  The index is whatever fp32 [rows, dim] blocks the caller keeps in HBM
+ * (Indexer.index_data, src/index.py:25-31, one block per call); a search walks the blocks in order:
+ *     czc_index_begin(state)  ->  czc_index_scan(block 0, fresh=1) -> czc_index_scan(block 1, fresh=0) ... ->
+ *     czc_index_finish(state -> scores fp32 [nq,k] descending, ids int64 [nq,k])
+ * State (device memory owned by the caller): cand_score fp32 [nq, cap], cand_id int32 [nq, cap],
+ * cand_count int32 [nq], tau fp32 [nq], with cap >= czc_index_candidate_capacity(k).
+ * Scores are fp32 products summed in fp32 (matrix cores, v_mfma_f32_32x32x2_f32); equal scores are ordered by
+ * ascending id; a result shorter than k is padded with id -1 and score -FLT_MAX as faiss does.
+ * dim % 16 == 0, 1 <= k <= 2048, id_base + rows < 2^31. */
+#define CZC_INDEX_CHUNK 65536
+int64_t czc_index_candidate_capacity(int32_t k);
+int czc_index_begin(int32_t* cand_count, float* tau, int32_t nq, czc_stream_t stream);
+int czc_index_scan(const float* db, int64_t rows, int32_t dim, int64_t id_base, const float* queries, int32_t nq,
+                   int32_t k, int32_t fresh, float* cand_score, int32_t* cand_id, int32_t* cand_count, float* tau,
+                   int64_t cap, czc_stream_t stream);
+int czc_index_finish(const float* cand_score, const int32_t* cand_id, const int32_t* cand_count, int64_t cap,
+                     int32_t nq, int32_t k, float* out_score, int64_t* out_id, czc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
