@@ -216,8 +216,12 @@ class FlatBertEncoder(nn.Module):
         ws = self._ws.get(key)
         if ws is None:
             n = int(L.load().czc_encoder_workspace_bytes(C.byref(self._shape), B, S, int(save)))
-            # keep at most one workspace per kind
-            for k in [k for k in self._ws if k[2] == int(save)]:
+            # keep at most one workspace per kind; an inference workspace that is large enough is kept as it is
+            # (passage encoding pads every batch to its own longest text: the shape changes with every call)
+            old = [k for k in self._ws if k[2] == int(save)]
+            if not save and old and self._ws[old[0]].numel() >= n:
+                return self._ws[old[0]]
+            for k in old:
                 del self._ws[k]
             ws = torch.empty(n, dtype=torch.uint8, device=self._flat.device)
             self._ws[key] = ws

@@ -74,3 +74,39 @@ class FlatIPIndex:
 
     def reconstruct_all(self) -> torch.Tensor:
         return torch.cat(self.blocks, 0) if self.blocks else torch.empty(0, self.dim, dtype=F32, device=self.device)
+
+
+# ---- `index.faiss` ------------------------------------------------------------------------------------------
+# faiss' own IndexFlatIP file layout (faiss/impl/index_write.cpp: fourcc "IxFI", d, ntotal, two dummies, is_trained,
+# metric_type 0 = inner product, then the float count and the floats), so that either side can read the other's file.
+# faiss is absent from this image: the layout is restated from its published source and only round-trips with itself
+# in the tests.
+_HEAD = "<iqqqBi"
+
+
+def write_faiss_flat(index: FlatIPIndex, path: str) -> None:
+    import struct
+    with open(path, "wb") as f:
+        f.write(b"IxFI")
+        f.write(struct.pack(_HEAD, index.dim, index.ntotal, 1 << 20, 1 << 20, 1, 0))
+        f.write(struct.pack("<Q", index.ntotal * index.dim))
+        for blk in index.blocks:
+            f.write(blk.cpu().numpy().tobytes())
+
+
+def read_faiss_flat(path: str) -> FlatIPIndex:
+    import struct
+    import numpy as np
+    with open(path, "rb") as f:
+        if f.read(4) != b"IxFI":
+            raise ValueError(f"{path}: not a flat inner-product index")
+        d, n, _, _, _, metric = struct.unpack(_HEAD, f.read(struct.calcsize(_HEAD)))
+        (count,) = struct.unpack("<Q", f.read(8))
+        if metric != 0 or count != n * d:
+            raise ValueError(f"{path}: metric {metric}, {count} floats for {n} x {d}")
+        index = FlatIPIndex(d)
+        step = max(1, (1 << 28) // d)   # 1 GiB of floats per block
+        for lo in range(0, n, step):
+            rows = min(step, n - lo)
+            index.add(torch.from_numpy(np.frombuffer(f.read(rows * d * 4), dtype=np.float32).reshape(rows, d).copy()))
+    return index

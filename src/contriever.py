@@ -18,10 +18,27 @@ from czech_contriever_amd.engine import FlatBertEncoder
 class Contriever(FlatBertEncoder):
     def __init__(self, config, pooling="average", **kwargs):
         super().__init__(config, pooling=pooling)
+        self._emb_dtype = torch.float32
+
+    def half(self):
+        """The reference's inference scripts call `model.half()` (generate_passage_embeddings.py:74-76,
+        passage_retrieval.py:153-155).  Here the matrix products already run in bf16 with fp32 accumulation from fp32
+        master weights, so nothing is cast: only the returned embeddings become fp16, as the reference's are."""
+        self._emb_dtype = torch.float16
+        return self
+
+    def float(self):
+        self._emb_dtype = torch.float32
+        return self
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None,
                 inputs_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None, output_attentions=None,
                 output_hidden_states=None, normalize=False):
+        if token_type_ids is not None:
+            # tokenizers hand back all-zero segment ids for single sentences; row 0 of the table is what the path adds
+            if bool(token_type_ids.any()):
+                raise NotImplementedError("the MI355X encoder path adds token type 0 only (got non-zero token_type_ids)")
+            token_type_ids = None
         unsupported = dict(token_type_ids=token_type_ids, position_ids=position_ids, head_mask=head_mask,
                            inputs_embeds=inputs_embeds, encoder_hidden_states=encoder_hidden_states,
                            encoder_attention_mask=encoder_attention_mask)
@@ -30,7 +47,8 @@ class Contriever(FlatBertEncoder):
             raise NotImplementedError(f"the MI355X encoder path takes input_ids + attention_mask only (got {bad})")
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids, dtype=torch.bool)
-        return self.encode(input_ids, attention_mask, normalize=normalize)
+        emb = self.encode(input_ids, attention_mask, normalize=normalize)
+        return emb if self._emb_dtype == torch.float32 else emb.to(self._emb_dtype)
 
 
 def _config_from(obj):

@@ -309,3 +309,23 @@ def load_data(opt, tokenizer, offsets=None, cumsums=None, is_main=False):
     if is_main and getattr(opt, "valid_data", None):
         val = Dataset(tokenize_jsonl_file(opt.valid_data[0], tokenizer, opt), opt.chunk_length, tokenizer, opt)
     return train, val
+
+
+def load_passages(path):
+    """Passage table for encoding / retrieval (reference src/data.py:656-673): `.jsonl` lines as they are, otherwise a
+    tab-separated file `id <TAB> text <TAB> title` whose header row (first field "id") is skipped."""
+    import csv
+    if not os.path.exists(path):
+        logger.info(f"{path} does not exist")
+        return
+    logger.info(f"Loading passages from: {path}")
+    passages = []
+    with open(path) as fin:
+        if path.endswith(".jsonl"):
+            for line in fin:
+                passages.append(json.loads(line))
+        else:
+            for row in csv.reader(fin, delimiter="\t"):
+                if row[0] != "id":
+                    passages.append({"id": row[0], "title": row[2], "text": row[1]})
+    return passages
