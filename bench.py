@@ -124,6 +124,103 @@ def cpu_baseline(seq, cpu_batch=8, steps=2):
                       f"bert-base, queue 8192, dropout on; median {med:.2f} s/step"}
 
 
+PEAK_FP32_MATRIX_TFLOPS = 157.3    # MI355X fp32 MFMA (MI355X_MICROARCH.md): 256 CUs x 256 FLOP/clk x 2.4 GHz
+
+
+def retrieval_bench(args):
+    """SURVEY §8 f3 / BASELINE.json config 5 on ONE GPU, not the headline: (A) eval-mode encoder forward over synthetic
+    256-token passages in batches of 512 (generate_passage_embeddings.py's default), (B) exact top-k inner-product search
+    of `--index-queries` queries against `--index-rows` fp32 vectors resident in HBM.  A "step" of the reported value is
+    one search batch."""
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+        raise SystemExit("--objective retrieval is a single-GPU diagnostic")
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    from czech_contriever_amd.flat_index import FlatIPIndex
+    from src.contriever import Contriever, bert_config
+    torch.manual_seed(0)
+    enc = Contriever(bert_config(**BERT_BASE)).to(device).eval().half()
+    g = torch.Generator().manual_seed(1234)
+    ids = [torch.randint(1000, 30522, (512, args.seq), generator=g, dtype=torch.int64).to(device) for _ in range(4)]
+    mask = torch.ones(512, args.seq, dtype=torch.bool, device=device)
+    with torch.no_grad():
+        for i in range(3):
+            enc(input_ids=ids[i % 4], attention_mask=mask)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_enc = max(4, args.steps)
+        for i in range(n_enc):
+            enc(input_ids=ids[i % 4], attention_mask=mask)
+        torch.cuda.synchronize()
+        enc_s = time.perf_counter() - t0
+    passages_per_s = 512 * n_enc / enc_s
+    log(f"encode: {passages_per_s:.0f} passages/s ({args.seq} tokens, batch 512)")
+    del enc
+    torch.cuda.empty_cache()
+
+    dim, rows, nq, k = 768, args.index_rows, args.index_queries, args.top_k
+    gd = torch.Generator(device=device).manual_seed(0)
+    ix = FlatIPIndex(dim)
+    for lo in range(0, rows, 1_000_000):           # passage_retrieval.py --indexing_batch_size
+        ix.add(torch.randn(min(1_000_000, rows - lo), dim, device=device, generator=gd) * 0.05)
+    q = torch.randn(nq, dim, device=device, generator=gd)
+    log(f"index: {rows} x {dim} fp32 = {rows * dim * 4 / 2**30:.1f} GiB in HBM")
+    for _ in range(max(1, args.warmup // 3)):
+        ix.search(q, k)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        scores, found = ix.search(q, k)
+    e1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1) / args.steps
+    flop = 2.0 * rows * nq * dim
+    tf = flop / (dev_ms * 1e-3) / 1e12
+
+    # parity inside the bench: a sample of the result against the oracle's float64 scores of the returned rows
+    sys.path.insert(0, ROOT)
+    from oracle import flat_index_oracle
+    import numpy as np
+    rsel = found[:8].cpu().numpy()
+    qs = q[:8].cpu().numpy().astype(np.float64)
+    vec = lambda r: ix.blocks[r // 1_000_000][r % 1_000_000]          # blocks were added 1 M rows at a time
+    exact = np.stack([torch.stack([vec(int(r)) for r in rsel[i]]).cpu().numpy().astype(np.float64) @ qs[i] for i in range(8)])
+    err = float(np.abs(exact - scores[:8].cpu().numpy()).max())
+    # CPU baseline: the oracle's fp32 sgemm + partial sort on a bounded slice of the same index, scaled by rows
+    sample = min(rows, 200_000)
+    dbs = ix.blocks[0][:sample].cpu().numpy()
+    qh = q.cpu().numpy()
+    threads = host_cpu_share()
+    from threadpoolctl import threadpool_limits
+    with threadpool_limits(limits=threads):
+        t1 = time.perf_counter()
+        flat_index_oracle.search_fp32_blas(dbs, qh, k)
+        cpu_s = time.perf_counter() - t1
+    out = {
+        "metric": "passage retrieval queries/sec (exact top-k over a flat fp32 inner-product index)",
+        "value": round(nq * args.steps / elapsed, 1), "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"NON-HEADLINE (BASELINE.json config 5): {rows} x {dim} fp32 passages in HBM, {nq} queries per search, top {k}; "
+                               f"encoder forward over synthetic {args.seq}-token passages, batch 512",
+                   "index_rows": rows, "dim": dim, "queries": nq, "top_k": k},
+        "encode_passages_per_s": round(passages_per_s, 1),
+        "encode_frac_bf16_peak": round(passages_per_s * 45.902e9 * (args.seq / 256.0) / (PEAK_BF16_TFLOPS * 1e12), 4),
+        "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tf / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": None,
+                     "kernel": f"czc::ip_scan_kernel (v_mfma_f32_32x32x2_f32) + czc::topk_compact_kernel, whole search: {flop / 1e12:.2f} TFLOP fp32 per step",
+                     "kernel_ms": round(dev_ms, 3)},
+        "max_abs_score_error_vs_f64": err,
+        "cpu_baseline": {"value": round(nq / (cpu_s * rows / sample), 2), "unit": "queries/s", "cores": threads, "kind": "port",
+                         "sample": f"oracle/flat_index_oracle.py search_fp32_blas (numpy sgemm + argpartition) on {sample} of the {rows} rows, "
+                                   f"{nq} queries: {cpu_s:.2f} s, scaled by rows"},
+    }
+    print(json.dumps(out), flush=True)
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -140,9 +237,15 @@ def main():
     ap.add_argument("--no-dropout", action="store_true", help="diagnostic only: the headline keeps dropout on")
     ap.add_argument("--ragged", action="store_true",
                     help="informational: sample lengths as the reference's random crops give them (27..130 of 256), pad id 0")
-    ap.add_argument("--objective", choices=("moco", "inbatch"), default="moco",
-                    help="inbatch = SURVEY §8 row f4 (one encoder, queries and keys both differentiable); not the headline")
+    ap.add_argument("--objective", choices=("moco", "inbatch", "retrieval"), default="moco",
+                    help="inbatch = SURVEY §8 row f4 (one encoder, queries and keys both differentiable); retrieval = row f3 "
+                         "(BASELINE.json config 5: passage encoding, then exact top-k over a flat fp32 index); neither is the headline")
+    ap.add_argument("--index-rows", type=int, default=10_000_000, help="retrieval: passages in the flat index (config 5: 10 M)")
+    ap.add_argument("--index-queries", type=int, default=2048, help="retrieval: queries per search (Indexer.search_knn's batch)")
+    ap.add_argument("--top-k", type=int, default=100, help="retrieval: passages returned per query (passage_retrieval.py --n_docs)")
     args = ap.parse_args()
+    if args.objective == "retrieval":
+        return retrieval_bench(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
