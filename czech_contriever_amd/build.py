@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libczc.so")
-SOURCES = ["api.cpp", "gemm_bf16.hip", "attention.hip", "rowops.hip", "head.hip", "optim.hip", "encoder.hip", "flat_index.hip"]
+SOURCES = ["api.cpp", "gemm_bf16.hip", "attention.hip", "rowops.hip", "head.hip", "optim.hip", "encoder.hip", "flat_index.hip", "distill.hip"]
 HEADERS = ["czc_common.h", "gemm_args.h", os.path.join("..", "..", "include", "czc.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 

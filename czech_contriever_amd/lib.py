@@ -67,6 +67,8 @@ SIGNATURES = {
     "czc_pool_forward": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     "czc_pool_backward": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "czc_dropout_mask": (i32, [u32, u32, f32, i64, vp, vp]),
+    "czc_distill_workspace_floats": (i64, [i32, i32, i32]),
+    "czc_distill_sim_loss": (i32, [vp, vp, i32, i32, i32, vp, i64, vp, vp, vp]),
     "czc_index_candidate_capacity": (i64, [i32]),
     "czc_index_begin": (i32, [vp, vp, i32, vp]),
     "czc_index_scan": (i32, [vp, i64, i32, i64, vp, i32, i32, i32, vp, vp, vp, vp, i64, vp]),

@@ -194,3 +194,32 @@ def enqueue(keys, queue_bf16, queue_f32, queue_ptr):
 def queue_import(queue_f32, queue_bf16):
     C_, K = queue_f32.shape
     L.check(_l().czc_queue_import(L.ptr(queue_f32, F32), C_, K, L.ptr(queue_bf16, BF16), L.stream_ptr()))
+
+
+class _DistillSimLoss(torch.autograd.Function):
+    """mean((Sn Sn^T - Tn Tn^T)^2) with its gradient w.r.t. the student embeddings from the same call (czc_distill_sim_loss)."""
+
+    @staticmethod
+    def forward(ctx, student, teacher):
+        B, D = student.shape
+        Dt = teacher.shape[1]
+        n = _l().czc_distill_workspace_floats(B, D, Dt)
+        ws = torch.empty(n, dtype=F32, device=student.device)
+        loss = torch.empty(1, dtype=F32, device=student.device)
+        grad = torch.empty_like(student) if student.requires_grad else None
+        L.check(_l().czc_distill_sim_loss(L.ptr(student, F32), L.ptr(teacher, F32), B, D, Dt, L.ptr(ws, F32), n,
+                                          L.ptr(loss, F32), L.ptr(grad, F32), L.stream_ptr()))
+        ctx.grad = grad
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None if ctx.grad is None else ctx.grad * g), None
+
+
+def distill_sim_loss(student, teacher):
+    """student fp32 [B, D] (may require grad), teacher fp32 [B, Dt] -> 0-d loss = F.mse_loss(sim(student), sim(teacher)),
+    sim(E) = normalize(E) @ normalize(E).T  (reference distill.py:44-47, 272-274)."""
+    if student.shape[0] != teacher.shape[0]:
+        raise ValueError(f"student {tuple(student.shape)} vs teacher {tuple(teacher.shape)}")
+    return _DistillSimLoss.apply(student.contiguous().float(), teacher.detach().contiguous().float())

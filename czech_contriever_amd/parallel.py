@@ -20,14 +20,14 @@ import torch.nn as nn
 from .engine import FlatBertEncoder
 
 
-def world():
-    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+def world(group=None):
+    return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
 
 
 @torch.no_grad()
 def average_(flat: torch.Tensor, group=None):
     """In-place mean over ranks of a flat gradient array."""
-    if world() == 1:
+    if world(group) == 1:
         return flat
     if dist.get_backend(group) == "nccl":
         dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
@@ -45,17 +45,20 @@ def average_(flat: torch.Tensor, group=None):
 class DataParallel(nn.Module):
     """`.module` is the wrapped MoCo (same attribute the reference reads from its DDP wrapper)."""
 
-    def __init__(self, module: nn.Module, optimizer=None, chunk_layers: int = 3):
+    def __init__(self, module: nn.Module, optimizer=None, chunk_layers: int = 3, process_group=None):
+        """process_group: the ranks that hold replicas (default: all; the students of a teacher/student run otherwise)."""
         super().__init__()
         self.module = module
+        self._group = process_group
+        self._world = world(process_group)
         self._encoders = [m for m in module.modules() if isinstance(m, FlatBertEncoder)
                           and any(p.requires_grad for p in m._plist)]
         self._comm = None
         self._done = None
         for enc in self._encoders:
             enc._range_hooks = [self._reduce_range]
-            enc.backward_chunk_layers = chunk_layers if world() > 1 else 0
-        if world() > 1 and torch.cuda.is_available():
+            enc.backward_chunk_layers = chunk_layers if self._world > 1 else 0
+        if self._world > 1 and torch.cuda.is_available():
             # The GEMMs' persistent launch sizes its grid to ALL the CUs; with RCCL's kernels holding some of them
             # during the overlapped gradient all-reduce the last workgroups would start a whole pass late.  One
             # workgroup per output tile degrades gracefully instead (include/czc.h, czc_gemm_set_tile).
@@ -72,7 +75,7 @@ class DataParallel(nn.Module):
 
     def _reduce_range(self, enc, lo, hi):
         """gradient elements [lo, hi) of the flat array are final: average them across ranks on the side stream"""
-        if world() == 1 or hi <= lo:
+        if self._world == 1 or hi <= lo:
             return
         g = enc.flat_grads(create=False)[lo:hi]
         if g.is_cuda:
@@ -82,11 +85,11 @@ class DataParallel(nn.Module):
             ready.record()
             with torch.cuda.stream(self._comm):
                 self._comm.wait_event(ready)
-                average_(g)
+                average_(g, self._group)
                 self._done = torch.cuda.Event()
                 self._done.record()
         else:
-            average_(g)
+            average_(g, self._group)
 
     def wait(self):
         if self._done is not None:

@@ -291,6 +291,15 @@ int czc_index_scan(const float* db, int64_t rows, int32_t dim, int64_t id_base, 
 int czc_index_finish(const float* cand_score, const int32_t* cand_id, const int32_t* cand_count, int64_t cap,
                      int32_t nq, int32_t k, float* out_score, int64_t* out_id, czc_stream_t stream);
 
+/* ---- similarity-matrix distillation loss -----------------------------------------------------------------------
+ * Replaces compute_sim_matrix x2 + F.mse_loss of the student side, reference distill.py:44-47,270-274:
+ *   loss[0] = mean_ij (Sn_i.Sn_j - Tn_i.Tn_j)^2, Sn / Tn = L2-normalised rows of student [batch, dim_student] /
+ *   teacher [batch, dim_teacher] (fp32);  d_student [batch, dim_student] = d loss / d student (NULL: loss only).
+ * The caller applies DISTILL_LOSS_MULTIPLIER and the distillation weight.  dim_student <= 4096. */
+int64_t czc_distill_workspace_floats(int32_t batch, int32_t dim_student, int32_t dim_teacher);
+int czc_distill_sim_loss(const float* student, const float* teacher, int32_t batch, int32_t dim_student, int32_t dim_teacher,
+                         float* workspace, int64_t workspace_floats, float* loss, float* d_student, czc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

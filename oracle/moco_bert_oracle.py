@@ -29,6 +29,9 @@ reference inherits through `class Contriever(BertModel)`, src/contriever.py:11-1
                       src/dist_utils.py:31-32; rank-order concat at world size W)
   step_stats()        src/moco.py:340-351
   inbatch_loss()      src/inbatch.py:59-90 (row f4: one encoder for queries and keys, in-batch negatives)
+  distill_sim_loss()  distill.py:44-47 (compute_sim_matrix) + :272-274 (mse of student vs teacher similarity matrices);
+                      distill.py itself cannot be imported here (clearml at import, Task.init at module level), so this
+                      three-line function is restated from the text: parity unpinned by the reference for row f2's loss
   warmup_linear()     src/utils.py:99-118
   adamw_step()        src/utils.py:137-150 -> torch.optim.AdamW semantics (decoupled decay)
 """
@@ -263,6 +266,13 @@ def inbatch_loss(qemb, kemb_all_ranks, rank, local_bsz, temperature, label_smoot
     return loss, acc, scores
 
 
+def distill_sim_loss(student, teacher):
+    def sim(e):
+        e = torch.nn.functional.normalize(e, p=2, dim=1)
+        return e @ e.T
+    return torch.nn.functional.mse_loss(sim(student), sim(teacher))
+
+
 def ema_update(Pk, Pq, momentum):
     for n in Pk:
         Pk[n] = Pk[n] * momentum + Pq[n] * (1.0 - momentum)
@@ -323,7 +333,9 @@ class MoCoState:
         self.v = {n: torch.zeros_like(t) for n, t in Pq.items()}
         self.opt_step = 0
 
-    def forward_backward(self, q_tokens, q_mask, k_tokens, k_mask, training=False):
+    def forward_backward(self, q_tokens, q_mask, k_tokens, k_mask, training=False, distill=None):
+        """distill = (teacher_embeddings, weight, multiplier): the student step of distill.py:263-278 — the gradient is
+        that of (1 - weight) * contrastive + weight * multiplier * distill_sim_loss(q, teacher)."""
         cfg = self.cfg
         q = encoder_forward(self.Pq, q_tokens, q_mask, cfg, self.pooling, self.norm_query, training)
         with torch.no_grad():
@@ -335,9 +347,16 @@ class MoCoState:
                 loss = loss + self.l2_from_init * ((p - self.P0[n]) ** 2).sum()
         with torch.no_grad():
             self.queue, self.ptr = enqueue(self.queue, self.ptr, k)
-        loss.backward()
+        extra = {}
+        if distill is None:
+            loss.backward()
+        else:
+            teacher, weight, mult = distill
+            aux = distill_sim_loss(q, teacher) * mult
+            ((1 - weight) * loss + weight * aux).backward()
+            extra["distill_loss"] = aux.detach()
         acc, stdq, stdk = step_stats(logits.detach(), q.detach(), k)
-        return loss.detach(), q.detach(), k, {"accuracy": acc, "stdq": stdq, "stdk": stdk}
+        return loss.detach(), q.detach(), k, dict({"accuracy": acc, "stdq": stdq, "stdk": stdk}, **extra)
 
     def optimizer_step(self, lr, beta1=0.9, beta2=0.98, eps=1e-6, weight_decay=0.01, keep_grads=False):
         self.opt_step += 1

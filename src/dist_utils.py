@@ -115,6 +115,14 @@ def sum_main(x):
     return x
 
 
+def sum_main_distill(x, process_group):
+    """Sum over the STUDENT ranks onto global rank 1, the students' main (reference :121-126; with a single student
+    there is nothing to add)."""
+    if _on() and dist.get_world_size() > 2:
+        dist.reduce(x, 1, op=dist.ReduceOp.SUM, group=process_group)
+    return x
+
+
 def average_main(x):
     if _on() and dist.get_world_size() > 1:
         dist.reduce(x, 0, op=dist.ReduceOp.SUM)
@@ -138,4 +146,16 @@ def weighted_average(x, count):
     d = _stat_device()
     t = torch.tensor([float(x) * float(count), float(count)], dtype=torch.float64 if d.type == "cpu" else torch.float32, device=d)
     sum_main(t)
+    return (t[0] / t[1]).item(), t[1].item()
+
+
+def weighted_average_distill(x, count, process_group):
+    """weighted_average over the student group, valid on global rank 1 (reference :128-137)."""
+    if not _on():
+        if isinstance(x, torch.Tensor):
+            x = x.item()
+        return x, count
+    d = _stat_device()
+    t = torch.tensor([float(x) * float(count), float(count)], dtype=torch.float64 if d.type == "cpu" else torch.float32, device=d)
+    sum_main_distill(t, process_group)
     return (t[0] / t[1]).item(), t[1].item()

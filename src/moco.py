@@ -184,13 +184,13 @@ class MoCo(nn.Module):
         ek.mark_mirror_fresh()
 
     @torch.no_grad()
-    def _dequeue_and_enqueue(self, keys):
-        """all-gather keys (rank order) and overwrite queue[:, ptr:ptr+n] (reference :272-287)."""
-        w = dist_utils.get_world_size()
+    def _dequeue_and_enqueue(self, keys, process_group=None):
+        """all-gather keys (rank order, over `process_group`) and overwrite queue[:, ptr:ptr+n] (reference :272-287)."""
+        w = dist_utils.get_world_size(process_group)
         if w > 1:
             if self._gather_buf is None or self._gather_buf.shape[0] != w * keys.shape[0]:
                 self._gather_buf = torch.empty(w * keys.shape[0], keys.shape[1], dtype=keys.dtype, device=keys.device)
-            keys = dist_utils.gather_nograd(keys.contiguous(), out=self._gather_buf)
+            keys = dist_utils.gather_nograd(keys.contiguous(), process_group, out=self._gather_buf)
         batch_size = keys.shape[0]
         assert self.queue_size % batch_size == 0, f"{batch_size}, {self.queue_size}"  # for simplicity
         qb = self._queue_mirror()
@@ -204,6 +204,10 @@ class MoCo(nn.Module):
         return torch.cat([l_pos, l_neg], dim=1)
 
     def forward(self, q_tokens, q_mask, k_tokens, k_mask, stats_prefix="", iter_stats={}, **kwargs):
+        loss, _, iter_stats = self._step(q_tokens, q_mask, k_tokens, k_mask, None, stats_prefix, iter_stats)
+        return loss, iter_stats
+
+    def _step(self, q_tokens, q_mask, k_tokens, k_mask, process_group, stats_prefix, iter_stats):
         bsz = q_tokens.size(0)
         q = self.encoder_q(input_ids=q_tokens, attention_mask=q_mask, normalize=self.norm_query)
 
@@ -231,7 +235,7 @@ class MoCo(nn.Module):
                 self._l2_anchor = torch.zeros(1, device=q.device, requires_grad=True)
             loss = loss + _L2FromInit.apply(self._l2_anchor, self.encoder_q, self._init_flat, float(self.weight_decay))
 
-        self._dequeue_and_enqueue(k)
+        self._dequeue_and_enqueue(k, process_group)
 
         if len(stats_prefix) > 0:
             stats_prefix = stats_prefix + "/"
@@ -239,8 +243,17 @@ class MoCo(nn.Module):
         iter_stats[f"{stats_prefix}accuracy"] = (stats[1], bsz)
         iter_stats[f"{stats_prefix}stdq"] = (stats[2], bsz)
         iter_stats[f"{stats_prefix}stdk"] = (stats[3], bsz)
-        return loss, iter_stats
+        return loss, q, iter_stats
 
     def init_weights_to_gpu(self):
         self.init_weights = {k: v.cuda() for k, v in self.init_weights.items()}
         self._init_flat = None
+
+
+class MoCoDistill(MoCo):
+    """The student of the teacher/student run (reference src/moco.py:15-184, driven by distill.py): MoCo whose key
+    all-gather runs over the students' process group and whose forward also hands back the query embeddings, still
+    attached to the graph, for the similarity-matrix loss against the teacher's (distill.py:263-276)."""
+
+    def forward(self, q_tokens, q_mask, k_tokens, k_mask, process_group, stats_prefix="", iter_stats={}, **kwargs):
+        return self._step(q_tokens, q_mask, k_tokens, k_mask, process_group, stats_prefix, iter_stats)

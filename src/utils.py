@@ -179,6 +179,26 @@ class WeightedAvgStats:
         return out
 
 
+class WeightedAvgStatsDistill(WeightedAvgStats):
+    """The same over the student ranks of a teacher/student run: keys come from global rank 1, sums go to it
+    (reference src/utils.py:177-220)."""
+
+    def __init__(self, process_group):
+        super().__init__()
+        self.process_group = process_group
+
+    @property
+    def average_stats(self) -> Dict[str, float]:
+        keys = sorted(self.raw_stats.keys())
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 2:
+            torch.distributed.broadcast_object_list(keys, src=1, group=self.process_group)
+        out = {}
+        for k in keys:
+            v = self.raw_stats[k] / self.total_weights[k] if k in self.total_weights else 0.0
+            out[k], _ = dist_utils.weighted_average_distill(v, self.total_weights[k], self.process_group)
+        return out
+
+
 def load_hf(object_class, model_name):
     """Local files only: there is no network on the target.  (reference :268-276 falls back to a download)"""
     if model_name == "czert":

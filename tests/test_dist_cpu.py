@@ -101,3 +101,58 @@ def test_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def _distill_worker(rank, world, port, out):
+    """Teacher (rank 0) + two students over gloo: the per-step exchange of distill.py on host tensors."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import distill
+        from src import dist_utils, utils
+        everyone = dist.new_group(list(range(world)))
+        control = dist.new_group(list(range(world)), backend="gloo")
+        students = dist.new_group(list(range(1, world)))
+        B, dim, pad, vocab, cpu = 4, 24, 0, 50, torch.device("cpu")
+        teacher = distill.SyntheticTeacher(dim, vocab, pad, cpu)
+        widths = {1: [7, 5, 9], 2: [6, 8, 9]}          # students crop to different lengths
+        if rank == 0:
+            served = distill.serve_teacher(teacher, everyone, control, B, cpu)
+            assert served == 3
+        else:
+            link = distill.StudentLink(everyone, control, B, dim, pad)
+            for step, w in enumerate(widths[rank]):
+                ids = O.det_ints((B, w), 300 + 10 * step + rank, 1, vocab)
+                assert link.send_ids(ids)
+                got = link.recv_embeddings(cpu)
+                # what the teacher saw: this student's ids padded to the longest of the step; padding is masked out
+                assert torch.allclose(got, teacher.encode_ids(ids), atol=1e-6)
+            # the students' own group: key gather in student order and the stats reduction onto global rank 1
+            keys = O.det_uniform((B, 8), 40 + rank)
+            allk = dist_utils.gather_nograd(keys, students)
+            assert torch.equal(allk, torch.cat([O.det_uniform((B, 8), 41), O.det_uniform((B, 8), 42)]))
+            st = utils.WeightedAvgStatsDistill(students)
+            st.update({"train/loss": (float(rank), 4 * rank)})
+            avg = st.average_stats
+            if rank == 1:
+                assert abs(avg["train/loss"] - (1 * 4 + 2 * 8) / 12) < 1e-6
+            assert not link.send_ids(None, stop=True)
+        out.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        out.put((rank, repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_teacher_student_exchange_world3_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_distill_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok"), (2, "ok")], res
