@@ -237,9 +237,10 @@ def main():
     ap.add_argument("--no-dropout", action="store_true", help="diagnostic only: the headline keeps dropout on")
     ap.add_argument("--ragged", action="store_true",
                     help="informational: sample lengths as the reference's random crops give them (27..130 of 256), pad id 0")
-    ap.add_argument("--objective", choices=("moco", "inbatch", "retrieval"), default="moco",
+    ap.add_argument("--objective", choices=("moco", "inbatch", "retrieval", "distill"), default="moco",
                     help="inbatch = SURVEY §8 row f4 (one encoder, queries and keys both differentiable); retrieval = row f3 "
-                         "(BASELINE.json config 5: passage encoding, then exact top-k over a flat fp32 index); neither is the headline")
+                         "(BASELINE.json config 5: passage encoding, then exact top-k over a flat fp32 index); distill = row f2 "
+                         "(the student's step of distill.py with a synthetic 3584-d teacher called in-process); none is the headline")
     ap.add_argument("--index-rows", type=int, default=10_000_000, help="retrieval: passages in the flat index (config 5: 10 M)")
     ap.add_argument("--index-queries", type=int, default=2048, help="retrieval: queries per search (Indexer.search_knn's batch)")
     ap.add_argument("--top-k", type=int, default=100, help="retrieval: passages returned per query (passage_retrieval.py --n_docs)")
@@ -270,7 +271,13 @@ def main():
         json.dump(cfg, f)
     opt = make_opt(mdir, args.batch, world, args.queue)
     torch.manual_seed(opt.seed)
-    model = (moco.MoCo(opt) if args.objective == "moco" else inbatch.InBatch(opt)).to(device)
+    if args.objective == "distill":
+        import distill
+        opt.distill_weight = 0.5
+        model = moco.MoCoDistill(opt).to(device)
+        teacher = distill.SyntheticTeacher(3584, cfg["vocab_size"], 0, device)
+    else:
+        model = (moco.MoCo(opt) if args.objective == "moco" else inbatch.InBatch(opt)).to(device)
     model.train()
     optimizer, scheduler = utils.set_optim(opt, model)
     model = DataParallel(model, optimizer)
@@ -279,8 +286,14 @@ def main():
         log(f"model on {device}, {sum(p.numel() for p in model.module.get_encoder().parameters())/1e6:.1f} M params/encoder; warm-up {args.warmup}")
 
     def step(i):
-        loss, _ = model(**batches[i % len(batches)], stats_prefix="train")
-        loss.backward()
+        if args.objective == "distill":   # distill.py's student: contrastive + similarity-matrix loss against the teacher
+            b = batches[i % len(batches)]
+            loss, q_emb, _ = model(**b, process_group=None, stats_prefix="train")
+            aux = distill.distill_loss(q_emb, teacher.encode_ids(b["q_tokens"]))
+            (0.5 * loss + 0.5 * aux).backward()
+        else:
+            loss, _ = model(**batches[i % len(batches)], stats_prefix="train")
+            loss.backward()
         optimizer.step()
         scheduler.step()
         model.zero_grad()
@@ -332,7 +345,7 @@ def main():
         headline = (args.batch == 256 and args.seq == 256 and args.queue == 131072 and not args.no_dropout
                     and args.objective == "moco" and not args.ragged)
         # in-batch: q fwd+bwd and k fwd+bwd = 6 encoder forwards' worth (275.4 G) + a 2*B*W*B*768 score product
-        flop_per_pair = FLOP_PER_PAIR if args.objective == "moco" else 6 * 45.902e9 * (args.seq / 256.0)
+        flop_per_pair = FLOP_PER_PAIR if args.objective in ("moco", "distill") else 6 * 45.902e9 * (args.seq / 256.0)
         out = {
             "metric": "contrastive pairs/sec (seq256, bsz256/GPU, queue131k)",
             "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -345,6 +358,8 @@ def main():
                        "parallelism": f"dp{world}", "weights": "random-init bert-base (seed 0)", "dropout": 0.0 if args.no_dropout else 0.1,
                        "step": "q fwd+bwd, EMA, k fwd, InfoNCE fwd+bwd, all-gather+enqueue, grad all-reduce, AdamW"
                                if args.objective == "moco" else
+                               "MoCo step + synthetic teacher embeddings (3584-d) + similarity-matrix MSE fwd+bwd"
+                               if args.objective == "distill" else
                                "q fwd+bwd, k fwd+bwd (same encoder), key all-gather with grad, in-batch CE, grad all-reduce, AdamW"},
             "roofline": {"bound": "mfma", "achieved": None if kern_tflops is None else round(kern_tflops, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
