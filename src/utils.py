@@ -29,32 +29,28 @@ logger = logging.getLogger(__name__)
 
 
 def mean_pooling(token_embeddings, mask):
-    token_embeddings = token_embeddings.masked_fill(~mask[..., None].bool(), 0.0)
-    return token_embeddings.sum(dim=1) / mask.sum(dim=1)[..., None]
+    """Masked mean over the sequence axis (the pooling of src/contriever.py:45-50, for callers that hold hidden states)."""
+    keep = mask.bool().unsqueeze(-1)
+    return torch.where(keep, token_embeddings, torch.zeros_like(token_embeddings)).sum(1) / mask.sum(1, keepdim=True)
 
 
 def init_logger(args, stdout_only=False):
+    """Root logging to stdout (+ <output_dir>/run.log), INFO on the main rank and WARN elsewhere (reference :25-38)."""
     dist_utils.barrier()
-    handlers = [logging.StreamHandler(sys.stdout)]
+    sinks = [logging.StreamHandler(sys.stdout)]
     if not stdout_only:
-        handlers.append(logging.FileHandler(filename=os.path.join(args.output_dir, "run.log")))
-    logging.basicConfig(
-        datefmt="%m/%d/%Y %H:%M:%S",
-        level=logging.INFO if dist_utils.is_main() else logging.WARN,
-        format="[%(asctime)s] {%(filename)s:%(lineno)d} %(levelname)s - %(message)s",
-        handlers=handlers,
-    )
+        sinks.append(logging.FileHandler(filename=os.path.join(args.output_dir, "run.log")))
+    level = logging.INFO if dist_utils.is_main() else logging.WARN
+    logging.basicConfig(level=level, handlers=sinks, datefmt="%m/%d/%Y %H:%M:%S",
+                        format="[%(asctime)s] {%(filename)s:%(lineno)d} %(levelname)s - %(message)s")
     return logger
 
 
 def symlink_force(target, link_name):
-    try:
-        os.symlink(target, link_name)
-    except OSError as e:
-        if e.errno != errno.EEXIST:
-            raise
+    """`ln -sfn`: an existing link (or file) of that name is replaced."""
+    if os.path.lexists(link_name):
         os.remove(link_name)
-        os.symlink(target, link_name)
+    os.symlink(target, link_name)
 
 
 def _unwrap(model):
