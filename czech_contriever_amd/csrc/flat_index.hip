@@ -15,6 +15,7 @@
 // Anything in the final top k beats the running k-th best at every point of the scan, so filtering by tau loses
 // nothing: the result equals a full sort of all N scores.
 #include "czc_common.h"
+#include "gemm_args.h"
 
 namespace czc {
 
@@ -201,12 +202,13 @@ __device__ __forceinline__ void ix_bitonic_desc(uint64_t* buf, int P, int tid, i
 // of the k are still to be found inside it.  One call per radix level.
 template <int BITS>
 __device__ __forceinline__ void ix_radix_level(const float* cs, int n, uint32_t prefix, int prefix_shift, int shift,
-                                               int* hist, int* part, int* sh, int tid, int nthreads) {
+                                               int* hist, int* part, int* sh, int tid, int nthreads,
+                                               const float* ce = nullptr) {
   constexpr int BINS = 1 << BITS;
   for (int i = tid; i < BINS; i += nthreads) hist[i] = 0;
   __syncthreads();
   for (int i = tid; i < n; i += nthreads) {
-    const uint32_t key = ix_key(cs[i]);
+    const uint32_t key = ix_key(ce ? cs[i] - ce[i] : cs[i]);
     if (prefix_shift >= 32 || (key >> prefix_shift) == prefix) atomicAdd(&hist[(key >> shift) & (BINS - 1)], 1);
   }
   __syncthreads();
@@ -306,6 +308,132 @@ __global__ void index_finish_kernel(const float* cand_score, const int* cand_id,
   out_id[i] = have ? (int64_t)cand_id[(int64_t)q * cap + j] : -1;
 }
 
+
+// ---- coarse (bf16) scan with error margins, then exact rescoring ----------------------------------------------
+// The scan above spends its time in fp32 MFMAs (157 TFLOP/s peak).  The same search with the SCORING done in bf16
+// (2.5 PFLOP/s class, the training GEMM of gemm_bf16.hip with a filter epilogue) and exactness kept by interval
+// arithmetic: a bf16 score c of query q and row d differs from the true inner product s by at most
+//   E(q, d) = IX_EPS * |q| * |d|      (two roundings to 8 significant bits: 2^-7 (1 + 2^-9) sum|q_i d_i| <= ... |q||d| by
+//                                      Cauchy-Schwarz, plus the fp32 accumulation of 768 terms; IX_EPS = 0.008)
+// so s lies in [c - E, c + E].  LB(q) = k-th largest lower bound seen so far is a lower bound of the final k-th score;
+// a row can only be in the top k if its upper bound reaches LB.  The scan keeps every such row (usually a few hundred
+// per query), the survivors are re-scored exactly in fp32 and the exact top k is selected as before: same result as
+// the fp32 scan, the matrix cores run ~6x faster.  A query whose survivor list outgrows its buffer is flagged and
+// must be searched with the fp32 scan instead.
+constexpr float IX_EPS = 0.008f;
+constexpr int IX_KEEP = 16384;   // survivors a query may carry from chunk to chunk
+
+__global__ __launch_bounds__(256) void index_prepare_kernel(const float* __restrict__ x, int64_t rows, int64_t rows_pad, int dim,
+                                                            float scale, bf16_t* __restrict__ xb, float* __restrict__ norms) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows_pad) return;
+  float ss = 0.f;
+  for (int d = lane * 4; d < dim; d += 256) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < rows) v = *(const float4*)(x + row * dim + d);
+    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    uint2 o;
+    o.x = pack2bf(v.x, v.y);
+    o.y = pack2bf(v.z, v.w);
+    *(uint2*)(xb + row * dim + d) = o;
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) norms[row] = scale * sqrtf(ss);
+}
+
+// first chunk of a search: the GEMM wrote c densely into cand_score[q][0..n); fill in the margins and the ids
+__global__ void coarse_fill_kernel(const float* __restrict__ qe, const float* __restrict__ dn, int n, int id_base, int64_t cap,
+                                   float* __restrict__ ce, int* __restrict__ ci) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
+  if (j >= n) return;
+  ce[(int64_t)q * cap + j] = qe[q] * dn[j];
+  ci[(int64_t)q * cap + j] = id_base + j;
+}
+
+// one workgroup per query: raise LB to the k-th largest lower bound, drop the entries whose upper bound is below it
+__global__ __launch_bounds__(512) void margin_compact_kernel(float* __restrict__ cand_score, float* __restrict__ cand_err,
+                                                            int* __restrict__ cand_id, int* __restrict__ cand_count,
+                                                            float* __restrict__ lb, int* __restrict__ flags, int64_t cap,
+                                                            int k, int dense_n) {
+  __shared__ int hist[2048];
+  __shared__ int part[512];
+  __shared__ int sh[4];
+  const int q = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
+  float* cs = cand_score + (int64_t)q * cap;
+  float* ce = cand_err + (int64_t)q * cap;
+  int* ci = cand_id + (int64_t)q * cap;
+  int n = dense_n >= 0 ? dense_n : cand_count[q];
+  bool overflow = false;
+  if ((int64_t)n > cap) { n = (int)cap; overflow = true; }
+  float bound = lb[q];
+  if (n >= k) {
+    if (tid == 0) sh[0] = k;
+    __syncthreads();
+    ix_radix_level<11>(cs, n, 0, 32, 21, hist, part, sh, tid, nthreads, ce);
+    const uint32_t b1 = (uint32_t)sh[1];
+    __syncthreads();
+    ix_radix_level<11>(cs, n, b1, 21, 10, hist, part, sh, tid, nthreads, ce);
+    const uint32_t p2 = (b1 << 11) | (uint32_t)sh[1];
+    __syncthreads();
+    ix_radix_level<10>(cs, n, p2, 10, 0, hist, part, sh, tid, nthreads, ce);
+    bound = fmaxf(bound, ix_unkey((p2 << 10) | (uint32_t)sh[1]));
+    __syncthreads();
+  }
+  // in-place compaction, a strip of `nthreads` entries at a time: a strip is read, then its survivors are written at or
+  // below where they were read
+  if (tid == 0) sh[2] = 0;
+  __syncthreads();
+  for (int s0 = 0; s0 < n; s0 += nthreads) {
+    const int i = s0 + tid;
+    float c = 0.f, e = 0.f;
+    int id = 0;
+    bool keep = false;
+    if (i < n) { c = cs[i]; e = ce[i]; id = ci[i]; keep = c + e >= bound; }
+    __syncthreads();
+    if (keep) {
+      const int p = atomicAdd(&sh[2], 1);
+      cs[p] = c; ce[p] = e; ci[p] = id;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    int m = sh[2];
+    if (m > IX_KEEP) { m = IX_KEEP; overflow = true; }
+    cand_count[q] = m;
+    lb[q] = bound;
+    if (overflow) flags[q] = 1;
+  }
+}
+
+// exact fp32 score of every surviving entry: one wave per entry
+__global__ __launch_bounds__(256) void rescore_kernel(const float* const* __restrict__ blocks, const int64_t* __restrict__ starts,
+                                                      int nblocks, int dim, const float* __restrict__ queries,
+                                                      float* __restrict__ cand_score, const int* __restrict__ cand_id,
+                                                      const int* __restrict__ cand_count, int64_t cap) {
+  const int q = blockIdx.y, lane = threadIdx.x & 63;
+  const int n = min((int64_t)cand_count[q], cap);
+  const float* qv = queries + (int64_t)q * dim;
+  for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += gridDim.x * 4) {
+    const int64_t id = cand_id[(int64_t)q * cap + e];
+    int b = 0;
+    while (b + 1 < nblocks && id >= starts[b + 1]) ++b;
+    const float* row = blocks[b] + (id - starts[b]) * dim;
+    float s = 0.f;
+    for (int d = lane * 4; d < dim; d += 256) {
+      const float4 a = *(const float4*)(qv + d), v = *(const float4*)(row + d);
+      s = fmaf(a.x, v.x, s); s = fmaf(a.y, v.y, s); s = fmaf(a.z, v.z, s); s = fmaf(a.w, v.w, s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) cand_score[(int64_t)q * cap + e] = s;
+  }
+}
+
+__global__ void coarse_begin_kernel(int* cand_count, float* lb, int* flags, int nq) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nq) { cand_count[i] = 0; lb[i] = -INFINITY; flags[i] = 0; }
+}
+
 static int ix_kpad(int k) { int p = 2; while (p < k) p <<= 1; return p; }
 
 }  // namespace czc
@@ -359,6 +487,89 @@ extern "C" int czc_index_finish(const float* cand_score, const int32_t* cand_id,
   const int64_t total = (int64_t)nq * k;
   hipLaunchKernelGGL(index_finish_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream,
                      cand_score, cand_id, cand_count, cap, nq, k, out_score, out_id);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
+// ---- coarse scan + rescoring entry points ------------------------------------------------------------------------
+extern "C" int64_t czc_index_coarse_capacity(int32_t k) {
+  if (k < 1 || k > IX_KMAX) return -1;
+  return (int64_t)IX_KEEP + CZC_INDEX_CHUNK;
+}
+
+extern "C" int czc_index_prepare(const float* x, int64_t rows, int32_t dim, float scale, uint16_t* x_bf16, float* norms,
+                                 czc_stream_t stream) {
+  CZC_REQUIRE(x && x_bf16 && norms && rows > 0, "czc_index_prepare: null pointer or rows=%lld", (long long)rows);
+  CZC_REQUIRE(dim > 0 && dim % IX_BK == 0, "czc_index_prepare: dim=%d must be a multiple of %d", dim, IX_BK);
+  const int64_t rows_pad = (rows + 7) / 8 * 8;
+  hipLaunchKernelGGL(index_prepare_kernel, dim3((unsigned)ceil_div64(rows_pad, 4)), dim3(256), 0, (hipStream_t)stream, x, rows,
+                     rows_pad, dim, scale, x_bf16, norms);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
+extern "C" float czc_index_coarse_epsilon(void) { return IX_EPS; }
+
+extern "C" int czc_index_coarse_begin(int32_t* cand_count, float* lower_bound, int32_t* flags, int32_t nq, czc_stream_t stream) {
+  CZC_REQUIRE(nq > 0 && cand_count && lower_bound && flags, "czc_index_coarse_begin: nq=%d", nq);
+  hipLaunchKernelGGL(coarse_begin_kernel, dim3(ceil_div(nq, 256)), dim3(256), 0, (hipStream_t)stream, cand_count, lower_bound, flags, nq);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
+extern "C" int czc_index_coarse_scan(const uint16_t* db_bf16, const float* db_norms, int64_t rows, int32_t dim, int64_t id_base,
+                                     const uint16_t* q_bf16, const float* q_margin, int32_t nq, int32_t k, int32_t fresh,
+                                     float* cand_score, float* cand_err, int32_t* cand_id, int32_t* cand_count,
+                                     float* lower_bound, int32_t* flags, int64_t cap, czc_stream_t stream) {
+  CZC_REQUIRE(db_bf16 && db_norms && q_bf16 && q_margin && cand_score && cand_err && cand_id && cand_count && lower_bound && flags,
+              "czc_index_coarse_scan: null pointer");
+  CZC_REQUIRE(rows > 0 && nq > 0, "czc_index_coarse_scan: rows=%lld nq=%d", (long long)rows, nq);
+  CZC_REQUIRE(dim > 0 && dim % IX_BK == 0, "czc_index_coarse_scan: dim=%d must be a multiple of %d", dim, IX_BK);
+  CZC_REQUIRE(k >= 1 && k <= IX_KMAX, "czc_index_coarse_scan: k=%d outside 1..%d", k, IX_KMAX);
+  CZC_REQUIRE(cap >= czc_index_coarse_capacity(k) && cap % 8 == 0 && cap < 0x7fffffffLL, "czc_index_coarse_scan: candidate capacity %lld",
+              (long long)cap);
+  CZC_REQUIRE(id_base >= 0 && id_base + rows <= 0x7fffffffLL, "czc_index_coarse_scan: passage rows beyond 2^31-1");
+  hipStream_t st = (hipStream_t)stream;
+  for (int64_t row0 = 0; row0 < rows; row0 += CZC_INDEX_CHUNK) {
+    const int n = (int)((rows - row0 < CZC_INDEX_CHUNK) ? rows - row0 : CZC_INDEX_CHUNK);
+    const int n_pad = (n + 7) / 8 * 8;          // the block's bf16 image is padded to 8 rows (czc_index_prepare)
+    const int dense = (fresh && row0 == 0) ? 1 : 0;
+    GemmArgs a{};
+    a.A = q_bf16; a.B = db_bf16 + row0 * dim;
+    a.M = nq; a.N = n_pad; a.K = dim;
+    a.lda = dim; a.ldb = dim;
+    int rc;
+    if (dense) {
+      a.C = cand_score; a.ldc = (int)cap;
+      rc = gemm_dispatch(0, 0, EPI_F32, a, 1, st);
+      if (rc != CZC_OK) return rc;
+      hipLaunchKernelGGL(coarse_fill_kernel, dim3(ceil_div(n, 256), nq), dim3(256), 0, st, q_margin, db_norms + row0, n,
+                         (int)(id_base + row0), cap, cand_err, cand_id);
+    } else {
+      a.ldc = 8;
+      a.f_lb = lower_bound; a.f_qe = q_margin; a.f_dn = db_norms + row0;
+      a.f_cs = cand_score; a.f_ce = cand_err; a.f_ci = cand_id; a.f_cnt = cand_count;
+      a.f_cap = cap; a.f_idbase = (int)(id_base + row0); a.f_nvalid = n;
+      rc = gemm_dispatch(0, 0, EPI_FILTER, a, 1, st);
+      if (rc != CZC_OK) return rc;
+    }
+    hipLaunchKernelGGL(margin_compact_kernel, dim3(nq), dim3(512), 0, st, cand_score, cand_err, cand_id, cand_count, lower_bound,
+                       flags, cap, k, dense ? n : -1);
+    CZC_LAUNCH_CHECK();
+  }
+  return CZC_OK;
+}
+
+extern "C" int czc_index_rescore(const float* const* blocks, const int64_t* block_starts, int32_t nblocks, int32_t dim,
+                                 const float* queries, int32_t nq, int32_t k, float* cand_score, int32_t* cand_id,
+                                 int32_t* cand_count, float* tau, int64_t cap, czc_stream_t stream) {
+  CZC_REQUIRE(blocks && block_starts && queries && cand_score && cand_id && cand_count && tau, "czc_index_rescore: null pointer");
+  CZC_REQUIRE(nblocks >= 1 && nq > 0 && dim > 0 && dim % 4 == 0 && k >= 1 && k <= IX_KMAX, "czc_index_rescore: nblocks=%d nq=%d dim=%d k=%d",
+              nblocks, nq, dim, k);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(rescore_kernel, dim3(64, nq), dim3(256), 0, st, blocks, block_starts, nblocks, dim, queries, cand_score,
+                     cand_id, cand_count, cap);
+  hipLaunchKernelGGL(topk_compact_kernel, dim3(nq), dim3(512), 0, st, cand_score, cand_id, cand_count, tau, cap, k, -1);
   CZC_LAUNCH_CHECK();
   return CZC_OK;
 }

@@ -20,6 +20,11 @@ struct GemmArgs {
   int cfg;               // tile configuration: 0 = default, 1 = 256x256 (8 waves), 2 = 128x128 (4 waves, 2 WG/CU)
   float alpha;           // head: 1/T
   float beta;            // head: eps/(K+1)
+  // EPI_FILTER (flat index, coarse bf16 scan): row m = query, column n = passage row of this chunk.  An entry is appended to
+  // query m's candidate list when its upper bound acc + f_qe[m] * f_dn[n] exceeds the query's lower bound f_lb[m].
+  const float* f_lb; const float* f_qe; const float* f_dn;
+  float* f_cs; float* f_ce; int* f_ci; int* f_cnt;
+  long long f_cap; int f_idbase; int f_nvalid;
 };
 
 #define EPI_STORE 0
@@ -31,6 +36,7 @@ struct GemmArgs {
 #define EPI_LSE 6       // head forward: per-row (max, sumexp, sum) partials of alpha*acc
 #define EPI_SOFTGRAD 7  // head backward: C = exp(alpha*acc - rowv[m]) - beta   (bf16)
 #define EPI_BIAS_GELU1 8 // C = gelu(acc + bias) only (inference / key encoder: the pre-activation is not kept)
+#define EPI_FILTER 9     // nothing is stored: accumulators that pass a per-row threshold are appended to per-row lists
 
 
 // checks shapes, picks the instantiation and launches; returns a CZC_* code

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   // second operand buffer only, so the first K-tile of the workgroup's NEXT output tile is already on its way into
   // the first buffer while this tile is written out: the ~3 us a tile otherwise waits for its first operands
   // (12 K-tiles of 1.7 us at K = 768) are hidden behind the stores.
-  constexpr bool PREFETCH = (EPI != EPI_F32 && EPI != EPI_LSE);
+  constexpr bool PREFETCH = (EPI != EPI_F32 && EPI != EPI_LSE && EPI != EPI_FILTER);
   const int ntiles = a.tiles_m * a.tiles_n;
   bool primed = false;   // K-tile 0 of the coming output tile was requested during the previous epilogue
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -655,6 +655,44 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
     continue;
   }
 
+  if (EPI == EPI_FILTER) {
+    // flat-index coarse scan: survivors are rare once the lower bounds have settled, so every lane appends its own
+    // (one atomic per survivor); the common case is 2 VALU ops per accumulator and no memory traffic at all
+    f32x4 dn[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = col0 + wn * WNC + 16 * j + 4 * nq;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dn[j][r] = (n + r < a.f_nvalid) ? a.f_dn[n + r] : -INFINITY;   // padded rows never pass
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = row0 + wm * TM * 16 + 16 * i + mrow;
+      const bool mok = m < a.M;
+      const float lb = mok ? a.f_lb[m] : INFINITY;
+      const float qe = mok ? a.f_qe[m] : 0.f;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = col0 + wn * WNC + 16 * j + 4 * nq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float c = acc[i][j][r];
+          const float e = qe * dn[j][r];
+          if (c + e > lb) {           // e = -inf for padded columns, lb = +inf for padded rows
+            const long long pos = atomicAdd(&a.f_cnt[m], 1);
+            if (pos < a.f_cap) {
+              const long long at = (long long)m * a.f_cap + pos;
+              a.f_cs[at] = c;
+              a.f_ce[at] = e;
+              a.f_ci[at] = a.f_idbase + n + r;
+            }
+          }
+        }
+      }
+    }
+    continue;
+  }
+
   // bf16 outputs: registers -> LDS (per-wave rows x 64 bf16 region, 16-B chunks XOR-swizzled by
   // row&7) -> 16-B row segments -> global
   // bias / row vector first, as bounds-checked buffer loads (out of range reads 0): all in flight together and
@@ -840,7 +878,7 @@ static int launch_cfg(GemmArgs a, int splits, hipStream_t st) {
   const int ntiles = a.tiles_m * a.tiles_n;
   // (measured, interleaved A/B at 65536 x {768, 2304, 3072}: persistent -1..-3 % for the bias / store / add / dGELU
   //  epilogues, +2 % for the two-output bias+GELU epilogue, which therefore keeps one workgroup per tile)
-  const bool persistent = (EPI != EPI_F32 && EPI != EPI_LSE && EPI != EPI_BIAS_GELU) && splits == 1 && !g_one_wg_per_tile;
+  const bool persistent = (EPI != EPI_F32 && EPI != EPI_LSE && EPI != EPI_BIAS_GELU && EPI != EPI_FILTER) && splits == 1 && !g_one_wg_per_tile;
   dim3 grid(persistent ? min(ntiles, slots) : ntiles, splits, 1);
   hipLaunchKernelGGL(kern, grid, dim3(CF::NT), CF::LDS, st, a);
   CZC_LAUNCH_CHECK();
@@ -905,7 +943,7 @@ static int gemm_dispatch_inner(int al, int bl, int epi, GemmArgs a, int splitk, 
   if (al == 1) CZC_REQUIRE((a.M % 8) == 0, "czc_gemm: M=%d must be a multiple of 8 for an M-major A", a.M);
   if (bl == 0) CZC_REQUIRE((a.K % 8) == 0, "czc_gemm: K=%d must be a multiple of 8 for a K-major B", a.K);
   CZC_REQUIRE(splitk >= 1, "czc_gemm: splitk=%d", splitk);
-  if (epi != EPI_F32 && epi != EPI_LSE)
+  if (epi != EPI_F32 && epi != EPI_LSE && epi != EPI_FILTER)
     CZC_REQUIRE((size_t)a.M * (size_t)a.ldc * 2u < 0xfffffff0ull,
                 "czc_gemm: a bf16 output of %d x %d exceeds the 4 GiB a buffer descriptor addresses", a.M, a.ldc);
   CZC_REQUIRE(splitk == 1 || epi == EPI_F32, "czc_gemm: split-K needs the f32 slab epilogue");
@@ -923,6 +961,9 @@ static int gemm_dispatch_inner(int al, int bl, int epi, GemmArgs a, int splitk, 
     case EPI_DGELU: CZC_REQUIRE(a.aux, "czc_gemm: dgelu epilogue needs aux"); return launch_layout<EPI_DGELU>(al, bl, a, splitk, st);
     case EPI_ADD: CZC_REQUIRE(a.aux, "czc_gemm: add epilogue needs aux"); return launch_layout<EPI_ADD>(al, bl, a, splitk, st);
     case EPI_F32: return launch_layout<EPI_F32>(al, bl, a, splitk, st);
+    case EPI_FILTER:
+      CZC_REQUIRE(al == 0 && bl == 0 && a.f_lb && a.f_qe && a.f_dn && a.f_cs && a.f_ce && a.f_ci && a.f_cnt, "czc_gemm: filter epilogue arguments");
+      return launch<0, 0, EPI_FILTER>(a, 1, st);
     case EPI_LSE:
       CZC_REQUIRE(al == 0 && bl == 0 && a.part, "czc_gemm: lse epilogue is K-major only");
       return launch<0, 0, EPI_LSE>(a, 1, st);

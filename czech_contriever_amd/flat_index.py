@@ -11,7 +11,11 @@ import torch
 
 from . import lib as L
 
-F32, I32, I64 = torch.float32, torch.int32, torch.int64
+F32, I32, I64, BF16 = torch.float32, torch.int32, torch.int64, torch.bfloat16
+
+
+def _pad8(n: int) -> int:
+    return (n + 7) // 8 * 8
 
 
 class FlatIPIndex:
@@ -23,8 +27,11 @@ class FlatIPIndex:
         self.dim = dim
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.blocks: List[torch.Tensor] = []
+        self.coarse: List[Tuple[torch.Tensor, torch.Tensor]] = []   # per block: bf16 image [ceil8(rows), dim], row norms
         self.ntotal = 0
         self._state = None   # (nq, k) -> candidate lists, reused between batches
+        self._cstate = None
+        self._table = None   # device arrays of block pointers / first rows for czc_index_rescore
 
     def add(self, x: torch.Tensor):
         """x: fp32 [n, dim], host or device; copied into its own HBM block."""
@@ -34,9 +41,20 @@ class FlatIPIndex:
             return
         if self.ntotal + x.shape[0] >= 2 ** 31:
             raise ValueError("flat index holds fewer than 2^31 vectors")
-        self.blocks.append(x.to(device=self.device, dtype=F32).contiguous().clone() if x.is_cuda
-                           else x.to(dtype=F32).contiguous().to(self.device))
+        blk = (x.to(device=self.device, dtype=F32).contiguous().clone() if x.is_cuda
+               else x.to(dtype=F32).contiguous().to(self.device))
+        self.blocks.append(blk)
+        self.coarse.append(self._prepare(blk, 1.0))
         self.ntotal += x.shape[0]
+        self._table = None
+
+    def _prepare(self, x: torch.Tensor, scale: float):
+        """bf16 image (padded to 8 rows) and scale * row norms of an fp32 [n, dim] device tensor (czc_index_prepare)."""
+        n = x.shape[0]
+        xb = torch.empty(_pad8(n), self.dim, dtype=BF16, device=self.device)
+        norms = torch.empty(_pad8(n), dtype=F32, device=self.device)
+        L.check(L.load().czc_index_prepare(L.ptr(x, F32), n, self.dim, scale, L.ptr(xb, BF16), L.ptr(norms, F32), L.stream_ptr()))
+        return xb, norms
 
     def _lists(self, nq: int, k: int):
         lib = L.load()
@@ -50,14 +68,67 @@ class FlatIPIndex:
                            torch.empty(nq, dtype=I32, device=self.device), torch.empty(nq, dtype=F32, device=self.device))
         return (cap,) + self._state[1:]
 
-    def search(self, queries: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    def search(self, queries: torch.Tensor, k: int, mode: str = "coarse") -> Tuple[torch.Tensor, torch.Tensor]:
         """queries fp32 [nq, dim] on the device -> (scores fp32 [nq,k] descending, rows int64 [nq,k]); both on the device.
-        Same result layout as faiss.IndexFlatIP.search (reference src/index.py:43), -1 / -FLT_MAX padded."""
-        lib = L.load()
+        Same result layout as faiss.IndexFlatIP.search (reference src/index.py:43), -1 / -FLT_MAX padded.
+        mode "coarse": bf16 scoring with error margins + exact fp32 rescoring of the survivors (same result, several
+        times faster; queries whose survivor list overflows are redone by the fp32 scan); "exact": the fp32 scan."""
         if queries.ndim != 2 or queries.shape[1] != self.dim:
             raise ValueError(f"expected [nq, {self.dim}], got {tuple(queries.shape)}")
-        nq = queries.shape[0]
+        if queries.shape[0] > 65535:
+            raise ValueError("at most 65535 queries per search call (Indexer.search_knn batches by index_batch_size)")
         q = queries.to(device=self.device, dtype=F32).contiguous()
+        if mode == "exact" or not self.blocks:
+            return self._search_exact(q, k)
+        if mode != "coarse":
+            raise ValueError(f"mode {mode!r}")
+        scores, rows, flags = self._search_coarse(q, k)
+        bad = torch.nonzero(flags).flatten()          # one host sync per search: the results are about to leave the GPU anyway
+        if bad.numel():
+            s2, r2 = self._search_exact(q[bad].contiguous(), k)
+            scores[bad], rows[bad] = s2, r2
+        return scores, rows
+
+    def _search_coarse(self, q: torch.Tensor, k: int):
+        lib = L.load()
+        nq = q.shape[0]
+        cap = lib.czc_index_coarse_capacity(k)
+        if cap < 0:
+            raise ValueError(f"k={k} outside 1..2048")
+        key = (nq, cap)
+        if self._cstate is None or self._cstate[0] != key:
+            dev = self.device
+            self._cstate = (key, torch.empty(nq, cap, dtype=F32, device=dev), torch.empty(nq, cap, dtype=F32, device=dev),
+                            torch.empty(nq, cap, dtype=I32, device=dev), torch.empty(nq, dtype=I32, device=dev),
+                            torch.empty(nq, dtype=F32, device=dev), torch.empty(nq, dtype=I32, device=dev),
+                            torch.empty(nq, dtype=F32, device=dev))
+        _, cs, ce, ci, cnt, lb, flags, tau = self._cstate
+        if self._table is None:
+            starts = [0]
+            for b in self.blocks:
+                starts.append(starts[-1] + b.shape[0])
+            self._table = (torch.tensor([b.data_ptr() for b in self.blocks], dtype=I64, device=self.device),
+                           torch.tensor(starts, dtype=I64, device=self.device))
+        qb, qmargin = self._prepare(q, float(lib.czc_index_coarse_epsilon()))
+        st = L.stream_ptr()
+        L.check(lib.czc_index_coarse_begin(L.ptr(cnt, I32), L.ptr(lb, F32), L.ptr(flags, I32), nq, st))
+        base = 0
+        for i, (blk, (xb, norms)) in enumerate(zip(self.blocks, self.coarse)):
+            L.check(lib.czc_index_coarse_scan(L.ptr(xb, BF16), L.ptr(norms, F32), blk.shape[0], self.dim, base, L.ptr(qb, BF16),
+                                              L.ptr(qmargin, F32), nq, k, int(i == 0), L.ptr(cs, F32), L.ptr(ce, F32),
+                                              L.ptr(ci, I32), L.ptr(cnt, I32), L.ptr(lb, F32), L.ptr(flags, I32), cap, st))
+            base += blk.shape[0]
+        L.check(lib.czc_index_rescore(L.ptr(self._table[0], I64), L.ptr(self._table[1], I64), len(self.blocks), self.dim,
+                                      L.ptr(q, F32), nq, k, L.ptr(cs, F32), L.ptr(ci, I32), L.ptr(cnt, I32), L.ptr(tau, F32), cap, st))
+        scores = torch.empty(nq, k, dtype=F32, device=self.device)
+        rows = torch.empty(nq, k, dtype=I64, device=self.device)
+        L.check(lib.czc_index_finish(L.ptr(cs, F32), L.ptr(ci, I32), L.ptr(cnt, I32), cap, nq, k, L.ptr(scores, F32),
+                                     L.ptr(rows, I64), st))
+        return scores, rows, flags
+
+    def _search_exact(self, q: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        lib = L.load()
+        nq = q.shape[0]
         cap, cs, ci, cnt, tau = self._lists(nq, k)
         st = L.stream_ptr()
         L.check(lib.czc_index_begin(L.ptr(cnt, I32), L.ptr(tau, F32), nq, st))

@@ -27,8 +27,15 @@ def _index(blocks):
     return ix
 
 
-def _search(ix, q, k):
-    s, r = ix.search(torch.from_numpy(q).cuda(), k)
+@pytest.fixture(params=["coarse", "exact"])
+def mode(request):
+    """coarse = bf16 scan with error margins + fp32 rescoring (the default); exact = the fp32 matrix-core scan.  Both
+    must give the oracle's answer."""
+    return request.param
+
+
+def _search(ix, q, k, mode="coarse"):
+    s, r = ix.search(torch.from_numpy(q).cuda(), k, mode=mode)
     torch.cuda.synchronize()
     return s.cpu().numpy(), r.cpu().numpy()
 
@@ -40,44 +47,44 @@ def _search(ix, q, k):
     ([3000, 3000], 5, 2048, 48),        # largest k, sort-only path
     ([90000], 3, 2048, 16),             # largest k through the radix select
 ])
-def test_integer_vectors_bit_exact(n_blocks, nq, k, dim):
+def test_integer_vectors_bit_exact(n_blocks, nq, k, dim, mode):
     rng = np.random.default_rng(sum(n_blocks) + nq + k)
     blocks = [rng.integers(-4, 5, (n, dim)).astype(np.float32) for n in n_blocks]
     q = rng.integers(-4, 5, (nq, dim)).astype(np.float32)
-    got_s, got_r = _search(_index(blocks), q, k)
+    got_s, got_r = _search(_index(blocks), q, k, mode)
     want_s, want_r = oracle.search(np.concatenate(blocks), q, k)
     assert np.array_equal(got_s, want_s)
     assert np.array_equal(got_r, want_r)
 
 
-def test_duplicated_passages_tie_by_row():
+def test_duplicated_passages_tie_by_row(mode):
     rng = np.random.default_rng(5)
     base = rng.integers(-3, 4, (50, 32)).astype(np.float32)
     db = np.tile(base, (1500, 1))                   # 75000 rows, every vector 1500 times: ties far beyond k
     q = rng.integers(-3, 4, (9, 32)).astype(np.float32)
-    got_s, got_r = _search(_index([db]), q, 100)
+    got_s, got_r = _search(_index([db]), q, 100, mode)
     want_s, want_r = oracle.search(db, q, 100)
     assert np.array_equal(got_s, want_s)
     assert np.array_equal(got_r, want_r)
 
 
-def test_short_index_is_padded_like_faiss():
+def test_short_index_is_padded_like_faiss(mode):
     rng = np.random.default_rng(1)
     db = rng.integers(-4, 5, (37, 16)).astype(np.float32)
     q = rng.integers(-4, 5, (4, 16)).astype(np.float32)
-    got_s, got_r = _search(_index([db]), q, 50)
+    got_s, got_r = _search(_index([db]), q, 50, mode)
     want_s, want_r = oracle.search(db, q, 50)
     assert np.array_equal(got_r, want_r) and np.array_equal(got_s, want_s)
     assert (got_r[:, 37:] == -1).all() and (got_s[:, 37:] == oracle.FLT_LOWEST).all()
 
 
-def test_real_vectors_within_fp32_summation_error():
+def test_real_vectors_within_fp32_summation_error(mode):
     rng = np.random.default_rng(11)
     n, dim, nq, k = 150_000, 768, 70, 100
     db = rng.standard_normal((n, dim), dtype=np.float32) * 0.05
     db[1::7] += 0.02                                # uneven score distribution, best rows spread over all chunks
     q = rng.standard_normal((nq, dim), dtype=np.float32)
-    got_s, got_r = _search(_index([db[:40_000], db[40_000:]]), q, k)
+    got_s, got_r = _search(_index([db[:40_000], db[40_000:]]), q, k, mode)
     exact = q.astype(np.float64) @ db.astype(np.float64).T
     bound = 2e-6 * (np.abs(q).astype(np.float64) @ np.abs(db).astype(np.float64).T)
     tol = np.take_along_axis(bound, got_r, 1)
@@ -88,6 +95,23 @@ def test_real_vectors_within_fp32_summation_error():
     kth = want_s[:, -1:].astype(np.float64)
     assert (np.take_along_axis(exact, got_r, 1) >= kth - 2 * bound.max()).all()   # nothing outside the top k was returned
     assert (got_r == want_r).mean() > 0.99          # and apart from near-ties the order is the oracle's
+
+
+def test_survivor_overflow_falls_back_to_the_fp32_scan():
+    """70 000 copies of one vector (+ a few better rows late in the index): every row is within the bf16 margin of the
+    k-th best, the survivor lists overflow, the flagged queries are redone by the fp32 scan — still the oracle's answer."""
+    rng = np.random.default_rng(9)
+    v = rng.integers(-3, 4, (1, 32)).astype(np.float32)
+    db = np.repeat(v, 70_000, 0)
+    db[[100, 66_000, 69_999]] *= 2.0
+    q = np.concatenate([v, -v, rng.integers(-3, 4, (3, 32)).astype(np.float32)])
+    ix = _index([db])
+    qd = torch.from_numpy(q).cuda()
+    _, _, flags = ix._search_coarse(qd, 100)
+    assert int(flags.sum()) >= 2                      # q = v and q = -v tie on (nearly) every row
+    got_s, got_r = _search(ix, q, 100, "coarse")
+    want_s, want_r = oracle.search(db, q, 100)
+    assert np.array_equal(got_s, want_s) and np.array_equal(got_r, want_r)
 
 
 def test_indexer_surface_and_file_round_trip(tmp_path):
