@@ -354,8 +354,8 @@ __global__ void coarse_fill_kernel(const float* __restrict__ qe, const float* __
 // one workgroup per query: raise LB to the k-th largest lower bound, drop the entries whose upper bound is below it
 __global__ __launch_bounds__(512) void margin_compact_kernel(float* __restrict__ cand_score, float* __restrict__ cand_err,
                                                             int* __restrict__ cand_id, int* __restrict__ cand_count,
-                                                            float* __restrict__ lb, int* __restrict__ flags, int64_t cap,
-                                                            int k, int dense_n) {
+                                                            float* __restrict__ lb, int* __restrict__ flags,
+                                                            int* __restrict__ kept, int64_t cap, int k, int dense_n, int force) {
   __shared__ int hist[2048];
   __shared__ int part[512];
   __shared__ int sh[4];
@@ -364,6 +364,10 @@ __global__ __launch_bounds__(512) void margin_compact_kernel(float* __restrict__
   float* ce = cand_err + (int64_t)q * cap;
   int* ci = cand_id + (int64_t)q * cap;
   int n = dense_n >= 0 ? dense_n : cand_count[q];
+  // the selection below costs ~10x the chunk's few appends: leave the list alone until it has doubled since it was last
+  // compacted (a stale bound is still a valid bound, it only lets a few more rows through) — unless the next chunk's
+  // worst case would no longer fit, or this is the last chunk
+  if (dense_n < 0 && !force && n <= IX_KEEP && n < 2 * kept[q] + 64) return;
   bool overflow = false;
   if ((int64_t)n > cap) { n = (int)cap; overflow = true; }
   float bound = lb[q];
@@ -401,6 +405,7 @@ __global__ __launch_bounds__(512) void margin_compact_kernel(float* __restrict__
     int m = sh[2];
     if (m > IX_KEEP) { m = IX_KEEP; overflow = true; }
     cand_count[q] = m;
+    kept[q] = m;
     lb[q] = bound;
     if (overflow) flags[q] = 1;
   }
@@ -429,9 +434,9 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* const* __rest
   }
 }
 
-__global__ void coarse_begin_kernel(int* cand_count, float* lb, int* flags, int nq) {
+__global__ void coarse_begin_kernel(int* cand_count, float* lb, int* flags, int* kept, int nq) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nq) { cand_count[i] = 0; lb[i] = -INFINITY; flags[i] = 0; }
+  if (i < nq) { cand_count[i] = 0; lb[i] = -INFINITY; flags[i] = 0; kept[i] = 0; }
 }
 
 static int ix_kpad(int k) { int p = 2; while (p < k) p <<= 1; return p; }
@@ -510,9 +515,11 @@ extern "C" int czc_index_prepare(const float* x, int64_t rows, int32_t dim, floa
 
 extern "C" float czc_index_coarse_epsilon(void) { return IX_EPS; }
 
-extern "C" int czc_index_coarse_begin(int32_t* cand_count, float* lower_bound, int32_t* flags, int32_t nq, czc_stream_t stream) {
-  CZC_REQUIRE(nq > 0 && cand_count && lower_bound && flags, "czc_index_coarse_begin: nq=%d", nq);
-  hipLaunchKernelGGL(coarse_begin_kernel, dim3(ceil_div(nq, 256)), dim3(256), 0, (hipStream_t)stream, cand_count, lower_bound, flags, nq);
+extern "C" int czc_index_coarse_begin(int32_t* cand_count, float* lower_bound, int32_t* flags, int32_t* kept, int32_t nq,
+                                      czc_stream_t stream) {
+  CZC_REQUIRE(nq > 0 && cand_count && lower_bound && flags && kept, "czc_index_coarse_begin: nq=%d", nq);
+  hipLaunchKernelGGL(coarse_begin_kernel, dim3(ceil_div(nq, 256)), dim3(256), 0, (hipStream_t)stream, cand_count, lower_bound, flags,
+                     kept, nq);
   CZC_LAUNCH_CHECK();
   return CZC_OK;
 }
@@ -520,8 +527,8 @@ extern "C" int czc_index_coarse_begin(int32_t* cand_count, float* lower_bound, i
 extern "C" int czc_index_coarse_scan(const uint16_t* db_bf16, const float* db_norms, int64_t rows, int32_t dim, int64_t id_base,
                                      const uint16_t* q_bf16, const float* q_margin, int32_t nq, int32_t k, int32_t fresh,
                                      float* cand_score, float* cand_err, int32_t* cand_id, int32_t* cand_count,
-                                     float* lower_bound, int32_t* flags, int64_t cap, czc_stream_t stream) {
-  CZC_REQUIRE(db_bf16 && db_norms && q_bf16 && q_margin && cand_score && cand_err && cand_id && cand_count && lower_bound && flags,
+                                     float* lower_bound, int32_t* flags, int32_t* kept, int64_t cap, czc_stream_t stream) {
+  CZC_REQUIRE(db_bf16 && db_norms && q_bf16 && q_margin && cand_score && cand_err && cand_id && cand_count && lower_bound && flags && kept,
               "czc_index_coarse_scan: null pointer");
   CZC_REQUIRE(rows > 0 && nq > 0, "czc_index_coarse_scan: rows=%lld nq=%d", (long long)rows, nq);
   CZC_REQUIRE(dim > 0 && dim % IX_BK == 0, "czc_index_coarse_scan: dim=%d must be a multiple of %d", dim, IX_BK);
@@ -554,7 +561,7 @@ extern "C" int czc_index_coarse_scan(const uint16_t* db_bf16, const float* db_no
       if (rc != CZC_OK) return rc;
     }
     hipLaunchKernelGGL(margin_compact_kernel, dim3(nq), dim3(512), 0, st, cand_score, cand_err, cand_id, cand_count, lower_bound,
-                       flags, cap, k, dense ? n : -1);
+                       flags, kept, cap, k, dense ? n : -1, 0);
     CZC_LAUNCH_CHECK();
   }
   return CZC_OK;

@@ -101,8 +101,8 @@ class FlatIPIndex:
             self._cstate = (key, torch.empty(nq, cap, dtype=F32, device=dev), torch.empty(nq, cap, dtype=F32, device=dev),
                             torch.empty(nq, cap, dtype=I32, device=dev), torch.empty(nq, dtype=I32, device=dev),
                             torch.empty(nq, dtype=F32, device=dev), torch.empty(nq, dtype=I32, device=dev),
-                            torch.empty(nq, dtype=F32, device=dev))
-        _, cs, ce, ci, cnt, lb, flags, tau = self._cstate
+                            torch.empty(nq, dtype=F32, device=dev), torch.empty(nq, dtype=I32, device=dev))
+        _, cs, ce, ci, cnt, lb, flags, tau, kept = self._cstate
         if self._table is None:
             starts = [0]
             for b in self.blocks:
@@ -111,12 +111,12 @@ class FlatIPIndex:
                            torch.tensor(starts, dtype=I64, device=self.device))
         qb, qmargin = self._prepare(q, float(lib.czc_index_coarse_epsilon()))
         st = L.stream_ptr()
-        L.check(lib.czc_index_coarse_begin(L.ptr(cnt, I32), L.ptr(lb, F32), L.ptr(flags, I32), nq, st))
+        L.check(lib.czc_index_coarse_begin(L.ptr(cnt, I32), L.ptr(lb, F32), L.ptr(flags, I32), L.ptr(kept, I32), nq, st))
         base = 0
         for i, (blk, (xb, norms)) in enumerate(zip(self.blocks, self.coarse)):
             L.check(lib.czc_index_coarse_scan(L.ptr(xb, BF16), L.ptr(norms, F32), blk.shape[0], self.dim, base, L.ptr(qb, BF16),
                                               L.ptr(qmargin, F32), nq, k, int(i == 0), L.ptr(cs, F32), L.ptr(ce, F32),
-                                              L.ptr(ci, I32), L.ptr(cnt, I32), L.ptr(lb, F32), L.ptr(flags, I32), cap, st))
+                                              L.ptr(ci, I32), L.ptr(cnt, I32), L.ptr(lb, F32), L.ptr(flags, I32), L.ptr(kept, I32), cap, st))
             base += blk.shape[0]
         L.check(lib.czc_index_rescore(L.ptr(self._table[0], I64), L.ptr(self._table[1], I64), len(self.blocks), self.dim,
                                       L.ptr(q, F32), nq, k, L.ptr(cs, F32), L.ptr(ci, I32), L.ptr(cnt, I32), L.ptr(tau, F32), cap, st))

@@ -76,8 +76,8 @@ SIGNATURES = {
     "czc_index_coarse_capacity": (i64, [i32]),
     "czc_index_coarse_epsilon": (f32, []),
     "czc_index_prepare": (i32, [vp, i64, i32, f32, vp, vp, vp]),
-    "czc_index_coarse_begin": (i32, [vp, vp, vp, i32, vp]),
-    "czc_index_coarse_scan": (i32, [vp, vp, i64, i32, i64, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i64, vp]),
+    "czc_index_coarse_begin": (i32, [vp, vp, vp, vp, i32, vp]),
+    "czc_index_coarse_scan": (i32, [vp, vp, i64, i32, i64, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     "czc_index_rescore": (i32, [vp, vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, i64, vp]),
 }
 

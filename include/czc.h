@@ -297,18 +297,18 @@ int czc_index_finish(const float* cand_score, const int32_t* cand_id, const int3
  * czc_index_coarse_epsilon() (the norms then are the queries' error margins).  Order of calls:
  *   czc_index_coarse_begin -> czc_index_coarse_scan per block (fresh=1 on the first) -> czc_index_rescore (exact fp32
  *   scores of the survivors + the exact top k at the head of the lists) -> czc_index_finish.
- * State: cand_score / cand_err fp32 [nq, cap], cand_id int32 [nq, cap], cand_count / flags int32 [nq], lower_bound / tau
+ * State: cand_score / cand_err fp32 [nq, cap], cand_id int32 [nq, cap], cand_count / flags / kept int32 [nq], lower_bound / tau
  * fp32 [nq], cap = czc_index_coarse_capacity(k).  flags[q] != 0 afterwards: query q's survivor list overflowed (masses
  * of near-identical scores) and its result is not valid — search it with czc_index_scan instead.
  * blocks / block_starts: DEVICE arrays of the fp32 block pointers and of their first row ids (nblocks + 1 entries). */
 int64_t czc_index_coarse_capacity(int32_t k);
 float czc_index_coarse_epsilon(void);
 int czc_index_prepare(const float* x, int64_t rows, int32_t dim, float scale, uint16_t* x_bf16, float* norms, czc_stream_t stream);
-int czc_index_coarse_begin(int32_t* cand_count, float* lower_bound, int32_t* flags, int32_t nq, czc_stream_t stream);
+int czc_index_coarse_begin(int32_t* cand_count, float* lower_bound, int32_t* flags, int32_t* kept, int32_t nq, czc_stream_t stream);
 int czc_index_coarse_scan(const uint16_t* db_bf16, const float* db_norms, int64_t rows, int32_t dim, int64_t id_base,
                           const uint16_t* q_bf16, const float* q_margin, int32_t nq, int32_t k, int32_t fresh,
                           float* cand_score, float* cand_err, int32_t* cand_id, int32_t* cand_count, float* lower_bound,
-                          int32_t* flags, int64_t cap, czc_stream_t stream);
+                          int32_t* flags, int32_t* kept, int64_t cap, czc_stream_t stream);
 int czc_index_rescore(const float* const* blocks, const int64_t* block_starts, int32_t nblocks, int32_t dim,
                       const float* queries, int32_t nq, int32_t k, float* cand_score, int32_t* cand_id, int32_t* cand_count,
                       float* tau, int64_t cap, czc_stream_t stream);
