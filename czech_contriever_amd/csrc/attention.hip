@@ -14,8 +14,10 @@
 //   dKdV      S = Q K^T, dP = dO V^T (query rows x key cols) -> dV^T += dO^T P~, dK^T += Q^T dS
 // K/V (or Q/dO) blocks are staged in LDS as [rows][64] bf16 with 16-B chunks XOR-swizzled by
 // swz64(row) so that both the ds_read_b128 row reads and the ds_read_b64_tr_b16 column reads are
-// bank-conflict free.  The backward is two kernels (5+... products recomputing S twice) rather than
-// one with a cross-wave / atomic dQ reduction: 0.8 % more FLOPs of the step, bitwise reproducible.
+// bank-conflict free.  Sequences longer than 256 keep a two-kernel backward (dQ; dK + dV: S, P~ and dS are rebuilt
+// in each); up to 256 tokens ONE workgroup per (batch, head) makes a single pass (attn_bwd_fused_kernel).
+#include <stdlib.h>
+
 #include "czc_common.h"
 
 namespace czc {
@@ -676,6 +678,291 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward, sequences of at most 256 tokens: dQ, dK and dV from ONE pass over the scores.
+// The two kernels above each rebuild S, P~ and dS (exp, dropout draws, conversions: they are VALU-bound, the MFMAs
+// wait); with the whole (batch, head) in one 512-thread workgroup that work is done once.  Wave w owns keys
+// 32w .. 32w+31 (K, V fragments and the dK, dV accumulators in registers, as in the dK/dV kernel); all Q and dO rows
+// sit in LDS; dQ is accumulated in LDS as fp32 [256][64].  In step s wave w works on query block (w + s) mod 8, so at
+// any time every block has exactly one writer: no atomics, and each dQ element receives its eight contributions in a
+// fixed order (bitwise reproducible, like the two-kernel form).  The dQ product contracts over KEYS while the dS tile
+// sits in accumulators as [query rows][key = lane]: it goes through a wave-private 2 KB LDS tile (bf16 [key][query],
+// one row per lane) and comes back as the transposed A operand; its B operand, this wave's K tile indexed
+// [key][d = lane], is loaded once from global memory in the matching k-order.
+// ---------------------------------------------------------------------------------------------
+// A operand [m = query = lane&31][k = key] from a wave's bf16 [32 keys][32 queries] tile (64-B rows), k-order of frag_tr
+__device__ __forceinline__ bf16x8 frag_tr64(const unsigned char* tile, int rbase, int lane) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3, h = g >> 1;
+  const int c = 2 * (g & 1) + (p >> 1);
+  const int row1 = rbase + 4 * h + q, row2 = row1 + 8;
+  typedef s16x4 __attribute__((address_space(3)))* trp_t;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(tile + row1 * 64 + (c << 4) + 8 * (p & 1)));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(tile + row2 * 64 + (c << 4) + 8 * (p & 1)));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const AttnArgs a) {
+  // one buffer: Q image 32 KB | dO image 32 KB | dQ accumulators 256 x 68 floats (68 KB; pitch 68: rows 4 banks apart) |
+  // per-wave dS tiles 16 KB | lse, delta 2 KB.  The epilogue reuses it from the start for the dK and dV tiles
+  // (2 x 256 rows x 68 floats = 136 KB) and the 8 KB after them for partial column sums.
+  constexpr int PITCH = 68;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[153600];
+  unsigned char* const qt = smem;
+  unsigned char* const dot = smem + 32768;
+  float* const dqs = (float*)(smem + 65536);
+  float* const lse_s = (float*)(smem + 151552);
+  float* const del_s = lse_s + 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, hh = blockIdx.y;
+  const int S = a.S, H3 = 3 * a.H;
+  const int k0 = wave * 32;
+  const int r = lane & 31, h = lane >> 5;
+  const bool active = k0 < S;   // wave-uniform
+  const float c2 = 0.125f * LOG2E;
+
+  const bf16_t* base = a.qkv + (size_t)b * S * H3 + hh * 64;
+  const bf16_t* dobase = a.dctx + (size_t)b * S * a.H + hh * 64;
+  const bf16_t* obase = a.ctx + (size_t)b * S * a.H + hh * 64;
+  const float* lsep = a.lse_in + ((size_t)b * a.nh + hh) * S;
+
+  // Every global load of the prologue is issued before the first use of any of them (one memory round trip): Q / dO
+  // rows for the LDS images, the O chunks that pair with this thread's dO chunks (delta), lse, the key's mask byte and
+  // this wave's K and V fragments.
+  uint4 qv[4], dv4[4], ov[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = tid + 512 * i, row = id >> 3, c = id & 7;
+    qv[i] = dv4[i] = ov[i] = (uint4){0u, 0u, 0u, 0u};
+    if (row < S) {
+      qv[i] = *(const uint4*)(base + (size_t)row * H3 + c * 8);
+      dv4[i] = *(const uint4*)(dobase + (size_t)row * a.H + c * 8);
+      ov[i] = *(const uint4*)(obase + (size_t)row * a.H + c * 8);
+    }
+  }
+  const float lse_v = (tid < S) ? lsep[tid] * LOG2E : 1.0e30f;
+  int kr = k0 + r; if (kr > S - 1) kr = S - 1;
+  const bool kvalid = (k0 + r) < S;
+  const uint8_t kmask = a.mask[(size_t)b * S + kr];
+  bf16x8 bk[4], bv[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    bk[ks] = ld_frag_global(base + a.H + (size_t)kr * H3 + 16 * ks + 8 * h);
+    bv[ks] = ld_frag_global(base + 2 * a.H + (size_t)kr * H3 + 16 * ks + 8 * h);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // Q and dO images (rows past S are zero); delta[row] = sum_d dO O: the eight threads that hold a row's chunks add up
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = tid + 512 * i, row = id >> 3, c = id & 7;
+    *(uint4*)(qt + row * 128 + ((c ^ swz64(row)) << 4)) = qv[i];
+    *(uint4*)(dot + row * 128 + ((c ^ swz64(row)) << 4)) = dv4[i];
+    const bf16x8 x = __builtin_bit_cast(bf16x8, dv4[i]), y = __builtin_bit_cast(bf16x8, ov[i]);
+    float dl = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dl += (float)x[j] * (float)y[j];
+    dl += dpp_mov<CZC_DPP_XOR1>(dl);
+    dl += dpp_mov<CZC_DPP_XOR2>(dl);
+    dl += dpp_mov<CZC_DPP_HALF_MIRROR>(dl);
+    if (c == 0) {
+      del_s[row] = dl;
+      if (row < S && a.delta) a.delta[((size_t)b * a.nh + hh) * S + row] = dl;
+    }
+  }
+  if (tid < 256) lse_s[tid] = lse_v;
+  // This wave's K tile once more as the B operand [k = key][n = d = 32dt + r] of the dQ product, keys in the
+  // accumulator-fed k-order: the fragments just loaded go through the wave's own slice of the (still unused) dQ
+  // accumulator area as a [32 keys][64 d] image and come back through transposing reads.  Then the slice is zeroed.
+  bf16x8 bkd[2][2];
+  {
+    unsigned char* kimg = (unsigned char*)(dqs + 32 * PITCH * wave);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      *(bf16x8*)(kimg + r * 128 + (((2 * ks + h) ^ swz64(r)) << 4)) = bk[ks];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) bkd[dt][ks] = frag_tr(kimg, 16 * ks, 32 * dt, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int i = lane; i < 32 * PITCH / 4; i += 64) *(f32x4*)(dqs + 32 * PITCH * wave + 4 * i) = (f32x4)(0.f);
+  }
+  const float kbias = (kvalid && kmask) ? 0.f : NEG_MASK;
+  f32x16 dk[2], dv[2];
+  dk[0] = dk[1] = dv[0] = dv[1] = (f32x16)(0.f);
+  const uint32_t S4 = (uint32_t)((S + 3) & ~3);
+  const uint32_t rkey = czc_rng_key(a.seed, a.site);
+  const uint32_t ebase = (uint32_t)((b * a.nh + hh) * S) * S4 + (uint32_t)(k0 + r);
+  unsigned char* my = smem + 135168 + wave * 2048;
+  __syncthreads();
+
+#pragma unroll 1
+  for (int step = 0; step < 8; ++step) {
+    const int qb = 32 * ((wave + step) & 7);
+    if (active && qb < S) {   // wave-uniform
+      f32x16 s = (f32x16)(0.f), dp = (f32x16)(0.f);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(qt, qb, ks, lane), bk[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(dot, qb, ks, lane), bv[ks], dp, 0, 0, 0);
+      }
+      // rows (registers) are queries qb + 8g + 4h + j, the lane is the key
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 l4 = *(const f32x4*)(&lse_s[qb + 8 * g + 4 * h]);
+        const f32x4 d4 = *(const f32x4*)(&del_s[qb + 8 * g + 4 * h]);
+        const f32x4 kl = kbias - l4;
+        czc_quad qd = {0u, 0u};   // one RNG quad per lane, shared inside each group of four lanes (see the dK/dV kernel)
+        if (DROP) qd = czc_rng_quad(rkey, (ebase + (uint32_t)(qb + 8 * g + 4 * h + (r & 3)) * S4) >> 2);
+        const uint32_t qlo[4] = {quad_bcast<0>(qd.lo), quad_bcast<1>(qd.lo), quad_bcast<2>(qd.lo), quad_bcast<3>(qd.lo)};
+        const uint32_t qhi[4] = {quad_bcast<0>(qd.hi), quad_bcast<1>(qd.hi), quad_bcast<2>(qd.hi), quad_bcast<3>(qd.hi)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[4 * g + j], c2, kl[j]));
+          float z = 1.f;
+          if (DROP) {
+            const uint32_t t = ((r & 2) ? qhi[j] : qlo[j]) << ((r & 1) ? 0 : 16);
+            z = t >= (a.thr << 16) ? a.inv_keep : 0.f;
+          }
+          const float dpz = z * dp[4 * g + j];
+          dp[4 * g + j] = p * (dpz - d4[j]);  // dS
+          s[4 * g + j] = p * z;               // P~
+        }
+      }
+      f32x16 dq[2];
+      dq[0] = dq[1] = (f32x16)(0.f);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = acc_frag(s, s2), df = acc_frag(dp, s2);
+        // dS^T tile row `r` (this lane's key): queries 16 s2 + 4h .. +3 and 16 s2 + 8 + 4h .. +3
+        const uint4 dw = __builtin_bit_cast(uint4, df);
+        *(uint2*)(my + r * 64 + 2 * (16 * s2 + 4 * h)) = make_uint2(dw.x, dw.y);
+        *(uint2*)(my + r * 64 + 2 * (16 * s2 + 8 + 4 * h)) = make_uint2(dw.z, dw.w);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot, qb + 16 * s2, 32 * dt, lane), pf, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, qb + 16 * s2, 32 * dt, lane), df, dk[dt], 0, 0, 0);
+        }
+      }
+      // dQ[query][d] += sum_key dS[query][key] K[key][d]
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 af = frag_tr64(my, 16 * ks, lane);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bkd[dt][ks], dq[dt], 0, 0, 0);
+      }
+      // dq[dt][i] = dQ[qb + 8(i>>2) + 4h + (i&3)][32dt + r]: this wave is the only writer of block qb in this step
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          // plain read-add-write (the block has one writer); ds_add_f32 measured 9x slower for the whole step
+          float* at = dqs + (qb + 8 * (i >> 2) + 4 * h + (i & 3)) * PITCH + 32 * dt + r;
+          *at += dq[dt][i];
+        }
+    }
+    __syncthreads();
+  }
+  // dQ: LDS fp32 -> bf16 rows (x 1/8), two threads per query; its bias gradient = column sums of the same numbers
+  // (rows past S were never added to: still zero)
+  float* const red = lse_s;                       // [3][64] Q, K, V column sums of dqkv; lse / delta are done with
+  float* const psum = (float*)(smem + 139264);    // [32][64] or [16][128] partial column sums
+  {
+    const int q = tid >> 1, half = tid & 1;
+    if (q < S) {
+      bf16_t* dstq = a.dqkv + ((size_t)b * S + q) * H3 + hh * 64 + 32 * half;
+      const float* src = dqs + q * PITCH + 32 * half;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 x = *(const f32x4*)(src + 8 * c), y = *(const f32x4*)(src + 8 * c + 4);
+        uint4 w;
+        w.x = pack2bf(x[0] * 0.125f, x[1] * 0.125f);
+        w.y = pack2bf(x[2] * 0.125f, x[3] * 0.125f);
+        w.z = pack2bf(y[0] * 0.125f, y[1] * 0.125f);
+        w.w = pack2bf(y[2] * 0.125f, y[3] * 0.125f);
+        *(uint4*)(dstq + 8 * c) = w;
+      }
+    }
+  }
+  if (a.dbias) {
+    const int quad = tid & 15, grp = tid >> 4;      // 16 column quads x 32 groups of 8 rows
+    f32x4 sq = (f32x4)(0.f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sq += *(const f32x4*)(dqs + (8 * grp + i) * PITCH + 4 * quad);
+    // (psum lies past the dQ rows: nothing else lives there now that the dS tiles are done with)
+    __syncthreads();
+    *(f32x4*)(psum + grp * 64 + 4 * quad) = sq;
+    __syncthreads();
+    if (tid < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 32; ++g) t += psum[g * 64 + tid];
+      red[tid] = t * 0.125f;
+    }
+  }
+  __syncthreads();
+  // dK (x 1/8) and dV tiles -> LDS as fp32 [256 keys][68] each (a lane owns a row; inactive waves and keys past S write
+  // zeros), then every thread sums columns for the bias gradient and packs 64-byte pieces of rows for dqkv
+  float* const dks = (float*)smem;
+  float* const dvs = dks + 256 * PITCH;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d0 = 32 * dt + 8 * g + 4 * h;
+      f32x4 x, y;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[j] = (active && kvalid) ? dk[dt][4 * g + j] * 0.125f : 0.f;
+        y[j] = (active && kvalid) ? dv[dt][4 * g + j] : 0.f;
+      }
+      *(f32x4*)(dks + (k0 + r) * PITCH + d0) = x;
+      *(f32x4*)(dvs + (k0 + r) * PITCH + d0) = y;
+    }
+  __syncthreads();
+  if (a.dbias) {
+    const int quad = tid & 31, grp = tid >> 5;      // 32 column quads (dK | dV) x 16 groups of 16 rows
+    const float* src = (quad < 16 ? dks : dvs) + 4 * (quad & 15);
+    f32x4 sk = (f32x4)(0.f);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sk += *(const f32x4*)(src + (16 * grp + i) * PITCH);
+    *(f32x4*)(psum + grp * 128 + 4 * quad) = sk;
+  }
+  {
+    const int row = tid >> 1, half = tid & 1;
+    if (row < S) {
+      bf16_t* dstk = a.dqkv + ((size_t)b * S + row) * H3 + a.H + hh * 64 + 32 * half;
+      bf16_t* dstv = dstk + a.H;
+      const float* sk = dks + row * PITCH + 32 * half;
+      const float* sv = dvs + row * PITCH + 32 * half;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 x = *(const f32x4*)(sk + 8 * c), y = *(const f32x4*)(sk + 8 * c + 4);
+        const f32x4 u = *(const f32x4*)(sv + 8 * c), v = *(const f32x4*)(sv + 8 * c + 4);
+        uint4 w;
+        w.x = pack2bf(x[0], x[1]); w.y = pack2bf(x[2], x[3]); w.z = pack2bf(y[0], y[1]); w.w = pack2bf(y[2], y[3]);
+        *(uint4*)(dstk + 8 * c) = w;
+        w.x = pack2bf(u[0], u[1]); w.y = pack2bf(u[2], u[3]); w.z = pack2bf(v[0], v[1]); w.w = pack2bf(v[2], v[3]);
+        *(uint4*)(dstv + 8 * c) = w;
+      }
+    }
+  }
+  if (a.dbias) {
+    __syncthreads();
+    if (tid < 128) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t += psum[g * 128 + tid];
+      red[64 + tid] = t;
+    }
+    __syncthreads();
+    if (tid < 192) {
+      float* row = a.dbias + (size_t)blockIdx.z * H3;
+      row[(tid >> 6) * a.H + hh * 64 + (tid & 63)] = red[tid];
+    }
+  }
+}
+
 static int attn_check(const char* who, int B, int S, int nh, float p) {
   CZC_REQUIRE(B > 0 && S > 0 && S <= 512 && nh > 0, "%s: batch=%d seq=%d heads=%d (seq <= 512)", who, B, S, nh);
   CZC_REQUIRE(p >= 0.f && p < 1.f, "%s: dropout_p=%f", who, p);
@@ -686,6 +973,8 @@ static int attn_check(const char* who, int B, int S, int nh, float p) {
 }  // namespace czc
 
 using namespace czc;
+
+static int g_attn_fused_bwd = -1;   // CZC_ATTN_FUSED_BWD=0 keeps the two-kernel backward for short sequences too (A/B runs)
 
 extern "C" int64_t czc_attention_bias_scratch_floats(int batch, int seq, int heads) {
   return (int64_t)batch * ceil_div(seq, 128) * 3 * heads * 64;
@@ -726,8 +1015,18 @@ extern "C" int czc_attention_backward(const uint16_t* qkv, const uint8_t* mask, 
   a.thr = dropout_p > 0.f ? czc_drop_thr(dropout_p) : 0u;
   a.inv_keep = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f;
   a.seed = seed; a.site = site;
-  dim3 grid(ceil_div(seq, 128), heads, batch);
   hipStream_t st = (hipStream_t)stream;
+  if (g_attn_fused_bwd < 0) { const char* e = getenv("CZC_ATTN_FUSED_BWD"); g_attn_fused_bwd = (e && e[0] == '0') ? 0 : 1; }
+  if (seq <= 256 && g_attn_fused_bwd) {   // one pass over the scores for dQ, dK and dV
+    dim3 grid1(1, heads, batch);
+
+    if (a.thr) hipLaunchKernelGGL(attn_bwd_fused_kernel<true>, grid1, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL(attn_bwd_fused_kernel<false>, grid1, dim3(512), 0, st, a);
+    CZC_LAUNCH_CHECK();
+    if (d_bias_qkv) return czc_reduce_partials(partials, batch, 3 * a.H, 3 * a.H, d_bias_qkv, stream);
+    return CZC_OK;
+  }
+  dim3 grid(ceil_div(seq, 128), heads, batch);
   if (a.thr) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, dim3(256), 0, st, a);
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, grid, dim3(256), 0, st, a);
