@@ -704,10 +704,11 @@ __device__ __forceinline__ bf16x8 frag_tr64(const unsigned char* tile, int rbase
 
 template <bool DROP>
 __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const AttnArgs a) {
-  // one buffer: Q image 32 KB | dO image 32 KB | dQ accumulators 256 x 68 floats (68 KB; pitch 68: rows 4 banks apart) |
-  // per-wave dS tiles 16 KB | lse, delta 2 KB.  The epilogue reuses it from the start for the dK and dV tiles
-  // (2 x 256 rows x 68 floats = 136 KB) and the 8 KB after them for partial column sums.
-  constexpr int PITCH = 68;
+  // one buffer: Q image 32 KB | dO image 32 KB | dQ accumulators, TRANSPOSED: 64 d-rows x 260 floats (65 KB; a lane's
+  // four consecutive queries of one d are one 16-byte access, rows 4 banks apart) | per-wave dS tiles 16 KB | lse, delta
+  // 2 KB.  The epilogue reuses it from the start for the dK and dV tiles (2 x 256 rows x 68 floats = 136 KB) and the
+  // 8 KB after them for partial column sums.
+  constexpr int PITCH = 68, QP = 260;
   __shared__ __attribute__((aligned(16))) unsigned char smem[153600];
   unsigned char* const qt = smem;
   unsigned char* const dot = smem + 32768;
@@ -776,7 +777,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const AttnArgs a
   // accumulator area as a [32 keys][64 d] image and come back through transposing reads.  Then the slice is zeroed.
   bf16x8 bkd[2][2];
   {
-    unsigned char* kimg = (unsigned char*)(dqs + 32 * PITCH * wave);
+    unsigned char* kimg = (unsigned char*)(dqs + 8 * QP * wave);     // this wave's slice: d-rows 8w .. 8w+7
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
       *(bf16x8*)(kimg + r * 128 + (((2 * ks + h) ^ swz64(r)) << 4)) = bk[ks];
@@ -785,7 +786,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const AttnArgs a
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) bkd[dt][ks] = frag_tr(kimg, 16 * ks, 32 * dt, lane);
     __builtin_amdgcn_sched_barrier(0);
-    for (int i = lane; i < 32 * PITCH / 4; i += 64) *(f32x4*)(dqs + 32 * PITCH * wave + 4 * i) = (f32x4)(0.f);
+    for (int i = lane; i < 8 * QP / 4; i += 64) *(f32x4*)(dqs + 8 * QP * wave + 4 * i) = (f32x4)(0.f);
   }
   const float kbias = (kvalid && kmask) ? 0.f : NEG_MASK;
   f32x16 dk[2], dv[2];
@@ -851,54 +852,51 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const AttnArgs a
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bkd[dt][ks], dq[dt], 0, 0, 0);
       }
-      // dq[dt][i] = dQ[qb + 8(i>>2) + 4h + (i&3)][32dt + r]: this wave is the only writer of block qb in this step
+      // dq[dt][4g + j] = dQ[qb + 8g + 4h + j][32dt + r]: this wave is the only writer of block qb in this step; plain
+      // 16-byte read-add-write per (dt, g) (ds_add_f32 measured 9x slower for the whole step)
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          // plain read-add-write (the block has one writer); ds_add_f32 measured 9x slower for the whole step
-          float* at = dqs + (qb + 8 * (i >> 2) + 4 * h + (i & 3)) * PITCH + 32 * dt + r;
-          *at += dq[dt][i];
+        for (int g = 0; g < 4; ++g) {
+          f32x4* at = (f32x4*)(dqs + (32 * dt + r) * QP + qb + 8 * g + 4 * h);
+          f32x4 v = *at;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += dq[dt][4 * g + j];
+          *at = v;
         }
     }
     __syncthreads();
   }
-  // dQ: LDS fp32 -> bf16 rows (x 1/8), two threads per query; its bias gradient = column sums of the same numbers
-  // (rows past S were never added to: still zero)
+  // dQ: LDS fp32 (transposed) -> bf16 rows (x 1/8), two threads per query; its bias gradient = sums of the same numbers
   float* const red = lse_s;                       // [3][64] Q, K, V column sums of dqkv; lse / delta are done with
-  float* const psum = (float*)(smem + 139264);    // [32][64] or [16][128] partial column sums
+  float* const psum = (float*)(smem + 139264);    // [16][128] partial column sums of the dK | dV tiles
   {
-    const int q = tid >> 1, half = tid & 1;
+    const int q = tid & 255, half = tid >> 8;     // consecutive lanes = consecutive queries: conflict-free column reads
     if (q < S) {
       bf16_t* dstq = a.dqkv + ((size_t)b * S + q) * H3 + hh * 64 + 32 * half;
-      const float* src = dqs + q * PITCH + 32 * half;
+      const float* src = dqs + 32 * half * QP + q;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const f32x4 x = *(const f32x4*)(src + 8 * c), y = *(const f32x4*)(src + 8 * c + 4);
         uint4 w;
-        w.x = pack2bf(x[0] * 0.125f, x[1] * 0.125f);
-        w.y = pack2bf(x[2] * 0.125f, x[3] * 0.125f);
-        w.z = pack2bf(y[0] * 0.125f, y[1] * 0.125f);
-        w.w = pack2bf(y[2] * 0.125f, y[3] * 0.125f);
+        w.x = pack2bf(src[(8 * c + 0) * QP] * 0.125f, src[(8 * c + 1) * QP] * 0.125f);
+        w.y = pack2bf(src[(8 * c + 2) * QP] * 0.125f, src[(8 * c + 3) * QP] * 0.125f);
+        w.z = pack2bf(src[(8 * c + 4) * QP] * 0.125f, src[(8 * c + 5) * QP] * 0.125f);
+        w.w = pack2bf(src[(8 * c + 6) * QP] * 0.125f, src[(8 * c + 7) * QP] * 0.125f);
         *(uint4*)(dstq + 8 * c) = w;
       }
     }
   }
   if (a.dbias) {
-    const int quad = tid & 15, grp = tid >> 4;      // 16 column quads x 32 groups of 8 rows
+    // Q part of the bias gradient: row sums of the transposed accumulators, eight threads per d (queries past S are 0)
+    const int d = tid >> 3, part = tid & 7;
     f32x4 sq = (f32x4)(0.f);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sq += *(const f32x4*)(dqs + (8 * grp + i) * PITCH + 4 * quad);
-    // (psum lies past the dQ rows: nothing else lives there now that the dS tiles are done with)
-    __syncthreads();
-    *(f32x4*)(psum + grp * 64 + 4 * quad) = sq;
-    __syncthreads();
-    if (tid < 64) {
-      float t = 0.f;
-#pragma unroll
-      for (int g = 0; g < 32; ++g) t += psum[g * 64 + tid];
-      red[tid] = t * 0.125f;
-    }
+    for (int i = 0; i < 8; ++i) sq += *(const f32x4*)(dqs + d * QP + 32 * part + 4 * i);
+    float t = (sq[0] + sq[1]) + (sq[2] + sq[3]);
+    t += dpp_mov<CZC_DPP_XOR1>(t);
+    t += dpp_mov<CZC_DPP_XOR2>(t);
+    t += dpp_mov<CZC_DPP_HALF_MIRROR>(t);
+    if (part == 0) red[d] = t * 0.125f;
   }
   __syncthreads();
   // dK (x 1/8) and dV tiles -> LDS as fp32 [256 keys][68] each (a lane owns a row; inactive waves and keys past S write
