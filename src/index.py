@@ -31,22 +31,28 @@ class Indexer(object):
             raise NotImplementedError("product-quantised index (faiss.IndexPQ) is not built on this path; use the flat index")
         self.index = flat_index.FlatIPIndex(vector_sz)
         self.index_id_to_db_id = []
+        self._names = None     # str(id) per row as one object array, built on first search after a change
 
     def index_data(self, ids, embeddings):
         self.index_id_to_db_id.extend(ids)
+        self._names = None
         self.index.add(_f32(embeddings))
         print(f'Total data indexed {len(self.index_id_to_db_id)}')
 
     def search_knn(self, query_vectors, top_docs: int, index_batch_size: int = 2048):
         queries = _f32(query_vectors)
-        names = self.index_id_to_db_id
+        if self._names is None or len(self._names) != len(self.index_id_to_db_id):
+            # the search itself takes ~40 ms per 2048 queries over 10 M passages: 200 000 str() calls per batch would
+            # cost more than that, so the ids are stringified once
+            self._names = np.array([str(x) for x in self.index_id_to_db_id], dtype=object)
         result = []
         for lo in range(0, len(queries), index_batch_size):
             part = queries[lo:lo + index_batch_size].to(self.index.device)
             scores, rows = self.index.search(part, top_docs)
             scores, rows = scores.cpu().numpy(), rows.cpu().numpy()
             # a short result's -1 rows index the id list from its end, as the reference's plain list lookup does
-            result += [([str(names[r]) for r in rows[i]], scores[i]) for i in range(len(rows))]
+            found = self._names[rows].tolist() if len(self._names) else [[] for _ in rows]
+            result += list(zip(found, scores))
         return result
 
     @staticmethod
@@ -66,6 +72,7 @@ class Indexer(object):
         self.index = flat_index.read_faiss_flat(index_file)
         with open(meta_file, 'rb') as f:   # the id list this class wrote next to the index
             self.index_id_to_db_id = pickle.load(f)
+        self._names = None
         if len(self.index_id_to_db_id) != self.index.ntotal:
             raise ValueError('Deserialized index_id_to_db_id should match faiss index size')
         print(f'Loaded flat index of size {self.index.ntotal}')
