@@ -57,6 +57,17 @@ def test_integer_vectors_bit_exact(n_blocks, nq, k, dim, mode):
     assert np.array_equal(got_r, want_r)
 
 
+@pytest.mark.parametrize("rows", [1, 7, 8, 9, 255, 257, 4099])
+def test_tiny_shapes(rows, mode):
+    rng = np.random.default_rng(rows)
+    for nq, k, dim in ((1, 1, 16), (3, 5, 32), (2, 300, 16)):
+        db = rng.integers(-4, 5, (rows, dim)).astype(np.float32)
+        q = rng.integers(-4, 5, (nq, dim)).astype(np.float32)
+        got_s, got_r = _search(_index([db]), q, k, mode)
+        want_s, want_r = oracle.search(db, q, k)
+        assert np.array_equal(got_s, want_s) and np.array_equal(got_r, want_r), (rows, nq, k, dim)
+
+
 def test_duplicated_passages_tie_by_row(mode):
     rng = np.random.default_rng(5)
     base = rng.integers(-3, 4, (50, 32)).astype(np.float32)
