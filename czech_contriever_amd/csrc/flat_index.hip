@@ -4,7 +4,11 @@
 // passage_retrieval.py:65-91,184-186).  Same contract: fp32 inner products, the k best per query in
 // descending score order.  Ties are ordered by ascending passage row (faiss leaves them unspecified).
 //
-// Two kernels per chunk of CZC_INDEX_CHUNK passage rows, all on the caller's stream, no host round trip:
+// Two ways through the index, same answer (tests run both against the oracle):
+//   czc_index_scan          every score on the fp32 matrix cores (below);
+//   czc_index_coarse_scan   scores on the bf16 matrix cores with a rigorous error margin per (query, row), survivors
+//                           re-scored in fp32 (second half of this file) — the default of the host side, ~6x faster.
+// The fp32 scan: two kernels per chunk of CZC_INDEX_CHUNK passage rows, all on the caller's stream, no host round trip:
 //   ip_scan_kernel     scores[128 queries x 256 rows] per workgroup on the fp32 matrix cores
 //                      (v_mfma_f32_32x32x2_f32: products and sums in fp32, as an sgemm would), and in the epilogue
 //                      every score ABOVE the query's running k-th best (tau) is appended to the query's candidate
