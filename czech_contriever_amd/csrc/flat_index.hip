@@ -216,17 +216,29 @@ __device__ __forceinline__ void ix_radix_level(const float* cs, int n, uint32_t 
     if (prefix_shift >= 32 || (key >> prefix_shift) == prefix) atomicAdd(&hist[(key >> shift) & (BINS - 1)], 1);
   }
   __syncthreads();
-  // partial sums of groups of 4 bins, then one thread walks down from the top
-  for (int i = tid; i < BINS / 4; i += nthreads) part[i] = hist[4 * i] + hist[4 * i + 1] + hist[4 * i + 2] + hist[4 * i + 3];
+  // sums of groups of 4 bins, their suffix sums (from the top bin down) by doubling, then the one thread whose group
+  // holds the wanted rank walks its 4 bins.  (A single thread walking down from the top bin took ~130 dependent LDS
+  // reads per level for ordinary positive scores: 15-20 us per call.)
+  constexpr int NG = BINS / 4;
+  for (int i = tid; i < NG; i += nthreads) part[i] = hist[4 * i] + hist[4 * i + 1] + hist[4 * i + 2] + hist[4 * i + 3];
   __syncthreads();
-  if (tid == 0) {
-    int need = sh[0];           // how many of the best are still wanted at this level (>= 1)
-    int g = BINS / 4 - 1;
-    while (g > 0 && part[g] < need) { need -= part[g]; --g; }
-    int b = 4 * g + 3;
-    while (b > 4 * g && hist[b] < need) { need -= hist[b]; --b; }
-    sh[0] = need;
-    sh[1] = b;
+  for (int off = 1; off < NG; off <<= 1) {
+    const int v = (tid < NG && tid + off < NG) ? part[tid + off] : 0;
+    __syncthreads();
+    if (tid < NG) part[tid] += v;
+    __syncthreads();
+  }
+  const int want = sh[0];       // how many of the best are still wanted at this level (>= 1)
+  __syncthreads();
+  if (tid < NG) {
+    const int incl = part[tid], excl = (tid + 1 < NG) ? part[tid + 1] : 0;
+    if (excl < want && want <= incl) {
+      int need = want - excl;
+      int b = 4 * tid + 3;
+      while (b > 4 * tid && hist[b] < need) { need -= hist[b]; --b; }
+      sh[0] = need;
+      sh[1] = b;
+    }
   }
   __syncthreads();
 }
@@ -541,10 +553,16 @@ extern "C" int czc_index_coarse_scan(const uint16_t* db_bf16, const float* db_no
               (long long)cap);
   CZC_REQUIRE(id_base >= 0 && id_base + rows <= 0x7fffffffLL, "czc_index_coarse_scan: passage rows beyond 2^31-1");
   hipStream_t st = (hipStream_t)stream;
-  for (int64_t row0 = 0; row0 < rows; row0 += CZC_INDEX_CHUNK) {
-    const int n = (int)((rows - row0 < CZC_INDEX_CHUNK) ? rows - row0 : CZC_INDEX_CHUNK);
-    const int n_pad = (n + 7) / 8 * 8;          // the block's bf16 image is padded to 8 rows (czc_index_prepare)
+  // The first chunk of a search is written densely and selected from in full (4 passes over n entries per query): it is
+  // kept short; after it the lower bounds exist and a chunk costs little more than its GEMM.  The last chunk of a call
+  // always compacts, so that czc_index_rescore re-scores survivors only.
+  constexpr int FIRST = 16384;
+  int64_t row0 = 0;
+  while (row0 < rows) {
     const int dense = (fresh && row0 == 0) ? 1 : 0;
+    const int64_t lim = dense ? FIRST : CZC_INDEX_CHUNK;
+    const int n = (int)((rows - row0 < lim) ? rows - row0 : lim);
+    const int n_pad = (n + 7) / 8 * 8;          // the block's bf16 image is padded to 8 rows (czc_index_prepare)
     GemmArgs a{};
     a.A = q_bf16; a.B = db_bf16 + row0 * dim;
     a.M = nq; a.N = n_pad; a.K = dim;
@@ -564,9 +582,11 @@ extern "C" int czc_index_coarse_scan(const uint16_t* db_bf16, const float* db_no
       rc = gemm_dispatch(0, 0, EPI_FILTER, a, 1, st);
       if (rc != CZC_OK) return rc;
     }
+    const int last = (row0 + n >= rows) ? 1 : 0;
     hipLaunchKernelGGL(margin_compact_kernel, dim3(nq), dim3(512), 0, st, cand_score, cand_err, cand_id, cand_count, lower_bound,
-                       flags, kept, cap, k, dense ? n : -1, 0);
+                       flags, kept, cap, k, dense ? n : -1, last);
     CZC_LAUNCH_CHECK();
+    row0 += n;
   }
   return CZC_OK;
 }
