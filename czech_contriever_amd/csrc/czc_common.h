@@ -162,24 +162,40 @@ __device__ __forceinline__ float gelu_f(float x) { return x * gelu_parts(x).cdf;
 // pad every exp / rcp with s_nops (37 per 8 elements in the GELU epilogues)
 template <bool DERIV>
 __device__ __forceinline__ void gelu8(const float (&x)[8], float (&out)[8]) {
-  float e[8], t[8], p[8];
+  // written on float pairs (v_pk_mul / v_pk_fma: two elements per VALU slot) and with the polynomial made monic
+  // (poly / a5 = (((t + b4) t + b3) t + b2) t + b1, a5 folded into the final 0.5): a packed fma takes ONE scalar
+  // constant, so the a5 t + a4 of the plain Horner form cost a constant move per pair
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 xv[4], e[4], t[4], p[4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(x[i] * x[i] * -0.72134752044448170368f);
+  for (int i = 0; i < 4; ++i) xv[i] = (f2){x[2 * i], x[2 * i + 1]};
 #pragma unroll
-  for (int i = 0; i < 8; ++i) t[i] = __builtin_amdgcn_rcpf(fmaf(fabsf(x[i]), 0.3275911f * 0.70710678118654752440f, 1.0f));
+  for (int i = 0; i < 4; ++i) {
+    const f2 q = xv[i] * xv[i] * -0.72134752044448170368f;
+    e[i] = (f2){__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+  }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) p[i] = fmaf(1.061405429f, t[i], -1.453152027f);
+  for (int i = 0; i < 4; ++i) {
+    const f2 az = (f2){fabsf(xv[i][0]), fabsf(xv[i][1])};
+    const f2 d = az * (0.3275911f * 0.70710678118654752440f) + 1.0f;
+    t[i] = (f2){__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) p[i] = fmaf(p[i], t[i], 1.421413741f);
+  for (int i = 0; i < 4; ++i) p[i] = t[i] + -1.3690829039465937f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) p[i] = fmaf(p[i], t[i], -0.284496736f);
+  for (int i = 0; i < 4; ++i) p[i] = p[i] * t[i] + 1.3391807712338357f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) p[i] = fmaf(p[i], t[i], 0.254829592f);
+  for (int i = 0; i < 4; ++i) p[i] = p[i] * t[i] + -0.2680377622225258f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float h = 0.5f * p[i] * t[i] * e[i];            // 0.5 * erfc(|x| / sqrt 2)
-    const float cdf = x[i] >= 0.f ? 1.0f - h : h;
-    out[i] = DERIV ? fmaf(x[i], 0.39894228040143267794f * e[i], cdf) : x[i] * cdf;
+  for (int i = 0; i < 4; ++i) p[i] = p[i] * t[i] + 0.24008694984732362f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f2 h = p[i] * t[i] * e[i] * 0.5307027145f;       // 0.5 * erfc(|x| / sqrt 2)
+    const f2 one_h = 1.0f - h;
+    const f2 cdf = (f2){xv[i][0] >= 0.f ? one_h[0] : h[0], xv[i][1] >= 0.f ? one_h[1] : h[1]};
+    const f2 o = DERIV ? xv[i] * (e[i] * 0.39894228040143267794f) + cdf : xv[i] * cdf;
+    out[2 * i] = o[0];
+    out[2 * i + 1] = o[1];
   }
 }
 __device__ __forceinline__ float dgelu_f(float x) {
