@@ -293,6 +293,74 @@ def g_inbatch(rc, ri):
     save("g10_inbatch.npz", **out)
 
 
+def g_base_grads(rc):
+    """bert-base-WIDTH gradients from the reference (H 768, 12 heads, I 3072, one layer, S 256, ragged): every parameter's
+    gradient of sum(emb * cot), subsampled (every `stride`-th element of the flattened tensor, <= 4096 values each) plus its
+    float64 sum and L2 norm, so the fixture stays small while every tensor is covered."""
+    cfg = O.BertShape(**BASE1)
+    seed, B, S = 23, 4, 256
+    P = O.make_params(cfg, seed)
+    ids, mask = ragged_batch(B, S, seed + 1, cfg.vocab_size, [256, 130, 27, 201])
+    cot = O.det_uniform((B, cfg.hidden_size), seed + 2)
+    out = {"ids": ids, "mask": mask, "seed": seed, "cot": cot}
+    for pooling, norm in (("average", False), ("average", True)):
+        enc = ref_encoder(rc, cfg, P, pooling)
+        emb = enc(input_ids=ids, attention_mask=mask, normalize=norm)
+        (emb * cot).sum().backward()
+        tag = f"{pooling}_{int(norm)}"
+        out[f"emb_{tag}"] = emb.detach()
+        for n, p in enc.named_parameters():
+            g = p.grad.reshape(-1)
+            stride = max(1, (g.numel() + 4095) // 4096)
+            out[f"grad_{tag}::{n}"] = g[::stride].clone()
+            out[f"gstat_{tag}::{n}"] = np.array([float(g.double().sum()), float(g.double().norm()), float(stride)])
+    save("g12_base_grads.npz", **out)
+
+
+def reference_function_from_text(path, names):
+    """Run chosen top-level definitions of a reference file that cannot be imported as a module (distill.py needs
+    clearml / sentence_transformers / beir at import and calls Task.init at module level): parse the file, keep only the
+    named `def`s and simple constant assignments, and execute those nodes -- the reference's own code, nothing restated
+    and nothing stubbed.  Build container only; nothing of the text is written anywhere."""
+    import ast
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    keep = []
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            keep.append(node)
+        elif isinstance(node, ast.Assign) and len(node.targets) == 1 and isinstance(node.targets[0], ast.Name) \
+                and node.targets[0].id in names and isinstance(node.value, ast.Constant):
+            keep.append(node)
+    found = {n.name if isinstance(n, ast.FunctionDef) else n.targets[0].id for n in keep}
+    assert found == set(names), (found, names)
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+def g_distill():
+    """Row f2's extra loss from the reference's own `compute_sim_matrix` and DISTILL_LOSS_MULTIPLIER (distill.py:30,44-47),
+    composed as its training loop does (distill.py:272-277: mse of the two similarity matrices, times the multiplier):
+    student [8, 768], teacher [8, 3584] -> loss and d loss / d student by autograd; a second, bert-batch-sized case
+    [64, 768] x [64, 3584] keeps only the loss and a subsample of the gradient."""
+    sim, mult = reference_function_from_text(os.path.join(REF, "distill.py"), ["compute_sim_matrix", "DISTILL_LOSS_MULTIPLIER"])
+    out = {"multiplier": float(mult)}
+    for tag, B in (("b8", 8), ("b64", 64)):
+        student = O.det_uniform((B, 768), 1201 + B, -0.5, 0.5).requires_grad_(True)
+        teacher = O.det_uniform((B, 3584), 1301 + B, -1.0, 1.0)
+        teacher[: B // 2] += 0.3 * teacher[B // 2: 2 * (B // 2)]       # correlated rows: off-diagonal similarities away from 0
+        aux = torch.nn.functional.mse_loss(sim(student), sim(teacher)) * mult
+        aux.backward()
+        out[f"{tag}_student_seed"] = 1201 + B
+        out[f"{tag}_teacher"] = teacher if B == 8 else teacher[:, ::16]
+        out[f"{tag}_teacher_full_checksum"] = float(teacher.double().sum())
+        out[f"{tag}_loss"] = aux.detach()
+        out[f"{tag}_dstudent"] = student.grad
+        out[f"{tag}_sim_teacher"] = sim(teacher)
+    save("g13_distill.npz", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -314,6 +382,8 @@ def main():
         "g8": lambda: g_trace(rc, rm, ru),
         "g9": lambda: g_trace(rc, rm, ru, "g9_moco_trace_norm.npz", norm=True, ls=0.1),
         "g10": lambda: g_inbatch(rc, ri),
+        "g12": lambda: g_base_grads(rc),
+        "g13": lambda: g_distill(),
     }
     for k, fn in jobs.items():
         if a.only and k not in a.only.split(","):

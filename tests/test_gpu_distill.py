@@ -169,3 +169,21 @@ def test_distill_cli_teacher_and_student_ranks(tmp_path):
     wa, wb = a["model"]["encoder_q.encoder.layer.1.output.dense.weight"], b["model"]["encoder_q.encoder.layer.1.output.dense.weight"]
     # three Adam steps of 1e-3 on the same data: equal up to summation order inside a few kernels (LDS / global float atomics)
     assert float((wa - wb).abs().mean()) < 2e-6 and float((wa - wb).abs().max()) < 5e-4, (float((wa - wb).abs().mean()), float((wa - wb).abs().max()))
+
+
+@pytest.mark.parametrize("tag", ["b8", "b64"])
+def test_sim_loss_kernel_matches_reference_golden(golden_dir, tag):
+    """czc_distill_sim_loss x DISTILL_LOSS_MULTIPLIER against what the reference's own compute_sim_matrix + mse x 100
+    produced (tests/golden/g13_distill.npz, oracle/make_golden.py g_distill; distill.py:30,44-47,272-277)."""
+    import numpy as np
+    from czech_contriever_amd.ops import distill_sim_loss
+    from tests.test_oracle_golden import distill_case
+    g = dict(np.load(os.path.join(golden_dir, "g13_distill.npz")))
+    student, teacher = distill_case(g, tag)
+    s_dev = student.cuda().requires_grad_(True)
+    aux = distill_sim_loss(s_dev, teacher.cuda()) * float(g["multiplier"])
+    aux.backward()
+    want = float(g[f"{tag}_loss"])
+    assert abs(float(aux.detach()) - want) <= 2e-5 * abs(want), (float(aux.detach()), want)
+    ref = torch.from_numpy(g[f"{tag}_dstudent"])
+    assert float((s_dev.grad.cpu() - ref).abs().max()) <= 5e-5 * float(ref.abs().max())

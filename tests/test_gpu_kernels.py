@@ -424,3 +424,59 @@ def test_infonce_head(ops, B, C, K, T, ls):
     report("lse", lse, torch.logsumexp(logits, 1), 2e-3, 1e-4)
     dq = ops.infonce_backward(q, k, qb, T, ls, lse, 1.0, ws)
     report("dq", dq, qq.grad, 2e-2 * float(qq.grad.abs().max()), 2e-2)
+
+
+@pytest.mark.parametrize("ls", [0.0, 0.1])
+def test_infonce_head_headline_size_vs_fp32_oracle(ops, ls):
+    """The bench / BASELINE config-2 head: B 256, C 768, K 131 072, T 0.05 (512 N-tiles of LSE partials, a 67 MB bf16
+    softmax-gradient matrix, a split-K dq) against the FP32 CPU oracle (oracle.infonce_loss on the fp32 q, k, queue --
+    not on the bf16-rounded operands the MFMA sees): loss, lse, accuracy, dq.  Reference: src/moco.py:289-294,323-330."""
+    from oracle import moco_bert_oracle as O
+    B, C, K, T = 256, 768, 131072, 0.05
+    q = (O.det_uniform((B, C), 901) * 0.7)
+    k = (O.det_uniform((B, C), 902) * 0.7)
+    k[: B // 2] = q[: B // 2] * 0.9 + 0.02          # half of the rows have an easy positive
+    queue = O.init_queue(C, K, 0)                   # normalize(randn(C, K), dim=0), seed 0: the bench's queue
+    qd, kd, queued = q.to(dev()), k.to(dev()), queue.to(dev())
+    qb = torch.empty(K, C, dtype=BF16, device=dev())
+    ops.queue_import(queued, qb)
+    ws = ops.infonce_workspace(B, C, K, dev())
+    lse, stats = ops.infonce_forward(qd, kd, qb, T, ls, ws)
+    dq = ops.infonce_backward(qd, kd, qb, T, ls, lse, 1.0, ws)
+    torch.cuda.synchronize()
+    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+    qq = q.clone().requires_grad_(True)
+    loss, logits = O.infonce_loss(qq, k, queue, T, ls)
+    loss.backward()
+    ref_lse = torch.logsumexp(logits.detach(), 1)
+    # bf16 q and queue: each negative logit carries ~2^-9 |q| / T ~ 0.05 of noise; the lse of 131 073 of them much less
+    assert abs(float(stats[0]) - float(loss)) < 2e-2 * max(1.0, abs(float(loss))), (float(stats[0]), float(loss))
+    report("lse @ K=131072", lse.cpu(), ref_lse, 5e-2, 1e-3)
+    acc = float(100 * (logits.argmax(-1) == 0).float().mean())
+    assert abs(float(stats[1]) - acc) <= 100.0 / B + 1e-4, (float(stats[1]), acc)     # at most one near-tie row differs
+    g, r = dq.cpu().double(), qq.grad.double()
+    cos_all = float(torch.nn.functional.cosine_similarity(g.reshape(-1), r.reshape(-1), dim=0))
+    assert cos_all >= 1 - 1e-3, cos_all
+    # row by row, for the rows that carry gradient (an easy positive leaves ~0)
+    big = r.norm(dim=1) > 1e-3 * float(r.norm(dim=1).max())
+    cos_rows = torch.nn.functional.cosine_similarity(g[big], r[big], dim=1)
+    assert float(cos_rows.min()) >= 1 - 5e-3, float(cos_rows.min())
+    assert abs(float(g.norm()) / float(r.norm()) - 1) < 2e-2
+
+
+def test_attention_fused_backward_is_bitwise_reproducible(ops):
+    """the single-pass backward (seq <= 256) adds the eight dQ contributions of a query block in a fixed order
+    and uses no atomics for dQ / dK / dV: two launches on the same inputs must agree bit for bit (dropout on)."""
+    B, S, nh, p, seed, site = 4, 256, 12, 0.1, 11, 16
+    H = nh * 64
+    qkv = rnd(B * S, 3 * H, seed=5, dtype=BF16)
+    mask = torch.ones(B, S, dtype=torch.bool, device=dev())
+    mask[1, 130:] = False
+    mask[3, 27:] = False
+    ctx, lse = ops.attention_forward(qkv, mask, B, S, nh, p, seed, site)
+    ctx2, lse2 = ops.attention_forward(qkv, mask, B, S, nh, p, seed, site)
+    assert torch.equal(ctx, ctx2) and torch.equal(lse, lse2)
+    dctx = rnd(B * S, H, seed=6, dtype=BF16)
+    a = ops.attention_backward(qkv, mask, ctx, dctx, lse, B, S, nh, p, seed, site)
+    b = ops.attention_backward(qkv, mask, ctx, dctx, lse, B, S, nh, p, seed, site)
+    assert torch.equal(a, b), float((a.float() - b.float()).abs().max())

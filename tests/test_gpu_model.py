@@ -314,3 +314,57 @@ def test_moco_checkpoint_layout_roundtrip(gpu, tmp_path):
     assert sd1["param_groups"] == sd2["param_groups"]
     for k in sd1["state"]:
         assert torch.equal(sd1["state"][k]["exp_avg"].cpu(), sd2["state"][k]["exp_avg"].cpu())
+
+
+def test_base_width_backward_vs_reference_golden(golden_dir, gpu):
+    """bert-base WIDTH (H 768, 12 heads, I 3072, S 256 ragged) backward against the REFERENCE's gradients (g12: a subsample
+    of every tensor + its L2 norm; made by oracle/make_golden.py from src.contriever.Contriever on HF BertModel)."""
+    g = load(golden_dir, "g12_base_grads.npz")
+    ids, mask, cot = t(g["ids"]).to(gpu), t(g["mask"]).to(gpu), t(g["cot"]).to(gpu)
+    for pooling, norm in (("average", False), ("average", True)):
+        enc, _, cfg_o = make_encoder(BASE1, int(g["seed"]), pooling, gpu)
+        enc.eval()
+        emb = enc(input_ids=ids, attention_mask=mask, normalize=norm)
+        tag = f"{pooling}_{int(norm)}"
+        assert float(cos_rows(emb.detach().cpu(), t(g[f"emb_{tag}"])).min()) >= 1 - 1e-3
+        (emb * cot).sum().backward()
+        gmax = max(float(np.abs(g[f"grad_{tag}::{n}"]).max()) for n, _ in enc.named_parameters())
+        num = da = db = 0.0
+        for n, p in enc.named_parameters():
+            stat = g[f"gstat_{tag}::{n}"]
+            ref = t(g[f"grad_{tag}::{n}"]).double()
+            got = p.grad.detach().reshape(-1)[::int(stat[2])].cpu().double()
+            scale = max(1e-2 * gmax, float(ref.abs().max()))
+            assert float((got - ref).abs().max()) <= 5e-2 * scale, (tag, n, float((got - ref).abs().max()), scale)
+            nrm = float(p.grad.detach().double().norm())
+            assert abs(nrm - stat[1]) <= 3e-2 * stat[1] + 1e-3 * gmax, (tag, n, nrm, stat[1])
+            num += float((got * ref).sum()); da += float((got * got).sum()); db += float((ref * ref).sum())
+        assert num / (da ** 0.5 * db ** 0.5) >= 1 - 2e-3, (tag, num / (da ** 0.5 * db ** 0.5))
+
+
+def test_bert_base_full_depth_backward_vs_oracle(gpu):
+    """The shapes the bench runs (12 layers, H 768, I 3072, 12 heads, S 256) at B = 8, ragged: every parameter gradient of
+    the HIP bf16 backward against the fp32 CPU oracle -- global cosine, and per-tensor cosine for the weight matrices."""
+    shape_kw = dict(vocab_size=2048, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                    intermediate_size=3072, max_position_embeddings=512)
+    enc, P, cfg_o = make_encoder(shape_kw, 77, "average", gpu)
+    enc.eval()
+    B = 8
+    ids, mask = ragged_batch(B, 256, 78, 2048, [256, 130, 27, 256, 77, 200, 1, 64])
+    cot = O.det_uniform((B, 768), 79)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    Pg = {n: v.clone().requires_grad_(True) for n, v in P.items()}
+    ref = O.encoder_forward(Pg, ids, mask, cfg_o, "average", False)
+    (ref * cot).sum().backward()
+    emb = enc(input_ids=ids.to(gpu), attention_mask=mask.to(gpu))
+    assert float(cos_rows(emb.detach().cpu(), ref.detach()).min()) >= 1 - 1e-3
+    (emb * cot.to(gpu)).sum().backward()
+    got = torch.cat([p.grad.reshape(-1) for p in enc.parameters()]).cpu().double()
+    want = torch.cat([Pg[n].grad.reshape(-1) for n, _ in O.param_names(cfg_o)]).double()
+    c = float(torch.nn.functional.cosine_similarity(got, want, dim=0))
+    assert c >= 1 - 3e-3, c
+    assert abs(float(got.norm()) / float(want.norm()) - 1) < 3e-2
+    worst = min((float(torch.nn.functional.cosine_similarity(p.grad.reshape(-1).cpu().double(), Pg[n].grad.reshape(-1).double(), dim=0)), n)
+                for n, p in enc.named_parameters() if n.endswith("dense.weight") or n.endswith("query.weight")
+                or n.endswith("key.weight") or n.endswith("value.weight"))
+    assert worst[0] >= 0.99, worst

@@ -146,3 +146,102 @@ def test_weight_decay_from_init_matches_oracle(tmp_path):
         st.optimizer_step(1e-2, weight_decay=0.0)
         assert abs(float(loss.detach()) - float(ref)) < 2e-2 * max(1.0, abs(float(ref))), (step, float(loss.detach()), float(ref))
     assert float(loss.detach()) > 1.0   # the penalty term is active (InfoNCE alone is < 1 here at step 2)
+
+
+BERT_BASE_UNCASED = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                         intermediate_size=3072, max_position_embeddings=512, type_vocab_size=2)
+
+
+def test_config1_sized_run_bert_base_uncased_on_jsonl(tmp_path, monkeypatch):
+    """BASELINE.json configs[0] at its STATED sizes: bert-base-uncased-sized encoder (12 layers, H 768, vocab 30 522),
+    chunk_length 64, per_gpu_batch_size 4, queue_size 512, 100 steps on a synthetic jsonl, through the command line
+    (jsonl -> WordPiece -> crops -> Collator -> DataLoader -> GPU micro-step -> AdamW -> checkpoint), dropout 0.1 on as
+    the reference trains.  Weights are random-init (no checkpoints offline) and the vocabulary is synthetic."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import random
+    import train
+    mdir = str(tmp_path / "bert-base-uncased")
+    os.makedirs(mdir)
+    with open(os.path.join(mdir, "config.json"), "w") as f:
+        json.dump(BERT_BASE_UNCASED, f)
+    words = [f"w{i}" for i in range(BERT_BASE_UNCASED["vocab_size"] - 5)]
+    with open(os.path.join(mdir, "vocab.txt"), "w") as f:
+        f.write("\n".join(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + words) + "\n")
+    rng = random.Random(1)
+    corpus = tmp_path / "corpus.jsonl"
+    with open(corpus, "w") as f:
+        for _ in range(600):                                   # >= 512 lines (SURVEY §8 d2, config A)
+            f.write(json.dumps({"text": " ".join(rng.choice(words) for _ in range(rng.randint(40, 200)))}) + "\n")
+    out = str(tmp_path / "run_config1")
+    args = ["--retriever_model_id", mdir, "--random_init", "--output_dir", out, "--save_dir", out, "--train_data", str(corpus),
+            "--chunk_length", "64", "--per_gpu_batch_size", "4", "--target_batch_size", "4", "--queue_size", "512",
+            "--temperature", "0.05", "--momentum", "0.9995", "--lr", "1e-5", "--warmup_steps", "20", "--total_steps", "100",
+            "--save_freq", "100", "--log_freq", "20", "--num_workers", "0"]
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    train.main(args)
+    ck = torch.load(os.path.join(out, "checkpoint", "step-100", "checkpoint.pth"), map_location="cpu", weights_only=False)
+    assert ck["step"] == 100 and int(ck["model"]["queue_ptr"]) == (100 * 4) % 512
+    assert tuple(ck["model"]["queue"].shape) == (768, 512)
+    assert len(ck["model"]) == 2 + 2 * 197                     # SURVEY §5: 396 tensors at bert-base
+    assert tuple(ck["model"]["encoder_q.embeddings.word_embeddings.weight"].shape) == (30522, 768)
+    for n, v in ck["model"].items():
+        assert torch.isfinite(v).all(), n
+    # every one of the 100 x 4 keys replaced an initial queue column... 400 of the 512 columns are encoder outputs now
+    q = ck["model"]["queue"]
+    assert float(((q[:, :400].norm(dim=0) - 1.0).abs() > 1e-3).float().mean()) > 0.99     # un-normalised keys (README flags)
+    assert float((q[:, 400:].norm(dim=0) - 1.0).abs().max()) < 1e-4                        # untouched initial columns
+
+
+def test_config1_sized_steps_match_oracle(tmp_path):
+    """The same sizes (bert-base-uncased shape incl. the 30 522-row vocabulary, S 64, B 4, K 512, README flags), dropout
+    off: three full micro-steps (q fwd/bwd, EMA, k fwd, InfoNCE, enqueue, AdamW) against the fp32 CPU oracle
+    (oracle.MoCoState): loss, accuracy, stdq / stdk, queue pointer, and the pooled q embeddings within 1e-3 cosine."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from src import moco, utils
+    dev = torch.device("cuda:0")
+    mdir = str(tmp_path / "bert-base-uncased")
+    os.makedirs(mdir)
+    with open(os.path.join(mdir, "config.json"), "w") as f:
+        json.dump(dict(BERT_BASE_UNCASED, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0), f)
+    opt = types.SimpleNamespace(
+        queue_size=512, momentum=0.9995, temperature=0.05, label_smoothing=0.0, norm_doc=False, norm_query=False,
+        moco_train_mode_encoder_k=False, weight_decay=0.01, weight_decay_from_init=False, retriever_model_id=mdir,
+        pooling="average", random_init=True, projection_size=768, optim="adamw", lr=1e-5, beta1=0.9, beta2=0.98,
+        eps=1e-6, warmup_steps=0, total_steps=100, lr_min_ratio=1.0, scheduler="linear")
+    model = moco.MoCo(opt)
+    cfg_o = O.BertShape(**BERT_BASE_UNCASED)
+    P = O.make_params(cfg_o, 91)
+    model.encoder_q.load_state_dict(P); model.encoder_k.load_state_dict(P)
+    queue = O.init_queue(768, 512, 0)
+    with torch.no_grad():
+        model.queue.copy_(queue)
+    model = model.to(dev).train()
+    optimizer, scheduler = utils.set_optim(opt, model)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    st = O.MoCoState(cfg_o, P, queue, momentum=0.9995, temperature=0.05)
+    B, S = 4, 64
+    for step in range(3):
+        qt, qm = ragged_batch(B, S, 9300 + step, 30522, [64, 41, 64, 17])
+        kt, km = ragged_batch(B, S, 9400 + step, 30522, [52, 64, 9, 64])
+        q_dev = None
+        if step == 0:
+            with torch.no_grad():
+                q_dev = model.encoder_q(input_ids=qt.to(dev), attention_mask=qm.to(dev)).cpu()
+        loss, stats = model(qt.to(dev), qm.to(dev), kt.to(dev), km.to(dev), stats_prefix="train", iter_stats={})
+        loss.backward()
+        optimizer.step(); scheduler.step(); model.zero_grad()
+        ref, q_ref, k_ref, rs = st.forward_backward(qt, qm, kt, km)
+        st.optimizer_step(1e-5)
+        if q_dev is not None:
+            c = torch.nn.functional.cosine_similarity(q_dev.double(), q_ref.double(), dim=-1)
+            assert float(c.min()) >= 1 - 1e-3, c
+        # un-normalised embeddings at T = 0.05: logits are O(100); bf16 operands give ~1e-2 relative on the loss
+        assert abs(float(loss.detach()) - float(ref)) < 3e-2 * max(1.0, abs(float(ref))), (step, float(loss.detach()), float(ref))
+        assert abs(float(stats["train/accuracy"][0]) - float(rs["accuracy"])) <= 25.0 + 1e-4     # B = 4: one near-tie row
+        assert abs(float(stats["train/stdq"][0]) - float(rs["stdq"])) < 1e-2 * max(1.0, float(rs["stdq"]))
+        assert abs(float(stats["train/stdk"][0]) - float(rs["stdk"])) < 1e-2 * max(1.0, float(rs["stdk"]))
+        assert int(model.queue_ptr) == st.ptr == ((step + 1) * B) % 512
+    assert float((model.queue.cpu() - st.queue).abs().max()) < 3e-2 * float(st.queue.abs().max())

@@ -156,3 +156,53 @@ def test_inbatch_matches_reference(golden_dir, tag):
         r = t(g[f"{tag}_grad::{n}"])
         scale = max(1e-6, float(r.abs().max()))
         assert float((p.grad - r).abs().max()) <= 3e-4 * scale + 1e-6, (tag, n)
+
+
+def base_grad_views(g, tag, named_grads):
+    """(name, subsampled gradient, reference subsample, reference [sum, norm, stride]) for fixture g12"""
+    for n, grad in named_grads:
+        stat = g[f"gstat_{tag}::{n}"]
+        stride = int(stat[2])
+        yield n, grad.reshape(-1)[::stride], t(g[f"grad_{tag}::{n}"]), stat
+
+
+def test_base_width_grads_match_reference(golden_dir):
+    """bert-base width (H 768, 12 heads, I 3072, S 256): every parameter gradient of the oracle against the reference's
+    (g12: subsample + float64 sum and L2 norm of each tensor)."""
+    g = load(golden_dir, "g12_base_grads.npz")
+    cfg = O.BertShape(**BASE1)
+    ids, mask, cot = t(g["ids"]), t(g["mask"]), t(g["cot"])
+    for pooling, norm in (("average", False), ("average", True)):
+        P = {n: v.requires_grad_(True) for n, v in O.make_params(cfg, int(g["seed"])).items()}
+        emb = O.encoder_forward(P, ids, mask, cfg, pooling, norm)
+        tag = f"{pooling}_{int(norm)}"
+        assert torch.allclose(emb, t(g[f"emb_{tag}"]), atol=ATOL, rtol=1e-4)
+        (emb * cot).sum().backward()
+        gmax = max(float(np.abs(g[f"grad_{tag}::{n}"]).max()) for n in P)
+        for n, sub, ref, stat in base_grad_views(g, tag, [(n, p.grad) for n, p in P.items()]):
+            scale = max(1e-3 * gmax, float(ref.abs().max()))
+            assert float((sub - ref).abs().max()) <= 5e-4 * scale, (tag, n, float((sub - ref).abs().max()), scale)
+            assert abs(float(P[n].grad.double().norm()) - stat[1]) <= 1e-4 * stat[1] + 1e-6 * gmax, (tag, n)
+
+
+def distill_case(g, tag):
+    B = 8 if tag == "b8" else 64
+    student = O.det_uniform((B, 768), int(g[f"{tag}_student_seed"]), -0.5, 0.5)
+    teacher = O.det_uniform((B, 3584), 1301 + B, -1.0, 1.0)
+    teacher[: B // 2] += 0.3 * teacher[B // 2: 2 * (B // 2)]
+    assert abs(float(teacher.double().sum()) - float(g[f"{tag}_teacher_full_checksum"])) < 1e-6
+    return student, teacher
+
+
+@pytest.mark.parametrize("tag", ["b8", "b64"])
+def test_distill_loss_matches_reference(golden_dir, tag):
+    """row f2: oracle.distill_sim_loss x multiplier against the reference's own compute_sim_matrix + mse x 100 (g13)"""
+    g = load(golden_dir, "g13_distill.npz")
+    student, teacher = distill_case(g, tag)
+    student.requires_grad_(True)
+    aux = O.distill_sim_loss(student, teacher) * float(g["multiplier"])
+    aux.backward()
+    assert float(g["multiplier"]) == 100.0
+    assert abs(float(aux) - float(g[f"{tag}_loss"])) <= 1e-5 * abs(float(g[f"{tag}_loss"]))
+    ref = t(g[f"{tag}_dstudent"])
+    assert float((student.grad - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
