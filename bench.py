@@ -2,7 +2,8 @@
 """bench.py — contrastive pairs/sec of the MoCo training micro-step on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1: either under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`, or bare:
+   `python bench.py --gpus N` starts that launcher itself as a child process, before anything here touches a GPU)
 
 One "step" = one full training micro-step of train.py's loop on one synthetic batch per GPU
 (BASELINE.json config 2/3): query-encoder forward + backward, momentum EMA, key-encoder forward,
@@ -29,6 +30,7 @@ import torch
 import torch.distributed as dist
 
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBPS = 8000.0             # HBM3E spec (same table); ~6.3 TB/s is what a float4 copy reaches
 FLOP_PER_PAIR = 184.01e9           # 4 x encoder fwd (45.902 G) + head 0.403 G
 
 BERT_BASE = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
@@ -233,6 +235,43 @@ def retrieval_bench(args):
     print(json.dumps(out), flush=True)
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: one rank process per GPU through torch.distributed.run (the
+    reference's launcher contract: torchrun env, train.py:428-430), started as a CHILD of this process -- which has not
+    touched a GPU and never will (a process that has initialised the GPU must not exec or fork ranks) -- on a free
+    loopback port.  Rank 0's JSON line goes to our stdout unchanged; our exit code is the launcher's."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"starting {n} ranks: {' '.join(cmd)}")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def kernel_table(rows, steps):
+    """czc_prof rows -> per-operation dicts (ms per step, achieved TFLOP/s or GB/s, fraction of the bound's peak),
+    largest first.  MFMA work is priced against the dense bf16 peak, byte-moving work against 8 TB/s HBM."""
+    out = []
+    for name, calls, ms, flops, nbytes in rows:
+        if calls == 0 or ms <= 0:
+            continue
+        per = ms / calls
+        d = {"name": name, "calls_per_step": round(calls / steps, 2), "ms_per_step": round(ms / steps, 4), "us_per_call": round(per * 1e3, 2)}
+        if flops > 0:
+            tf = flops / (per * 1e-3) / 1e12
+            d.update(bound="mfma", tflops=round(tf, 1), frac=round(tf / PEAK_BF16_TFLOPS, 4), gflop_per_call=round(flops / 1e9, 2))
+        else:
+            gbs = nbytes / (per * 1e-3) / 1e9
+            d.update(bound="hbm", gbps=round(gbs, 1), frac=round(gbs / PEAK_HBM_GBPS, 4), mbytes_per_call=round(nbytes / 1e6, 2))
+        out.append(d)
+    out.sort(key=lambda d: -d["ms_per_step"])
+    return out
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -246,6 +285,8 @@ def main():
     ap.add_argument("--seq", type=int, default=256, help="chunk_length (headline: 256)")
     ap.add_argument("--queue", type=int, default=131072)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-table", type=int, default=3,
+                    help="steps run AFTER the timed region with per-operation hipEvents, for roofline.kernels (0 = skip)")
     ap.add_argument("--no-dropout", action="store_true", help="diagnostic only: the headline keeps dropout on")
     ap.add_argument("--ragged", action="store_true",
                     help="informational: sample lengths as the reference's random crops give them (27..130 of 256), pad id 0")
@@ -263,8 +304,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args.gpus)
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} under a launcher with WORLD_SIZE={world}: the two must agree")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -343,17 +386,40 @@ def main():
     L.check(lib.czc_probe_read(ctypes.byref(tot_ms), ctypes.byref(cnt)))
     L.check(lib.czc_probe_arm(0, 0, 0, 0, 0, 0, 0))
 
+    # per-operation table: a few more steps, OUTSIDE the timed region, with a hipEvent pair around every operation
+    kernels = None
+    if rank == 0 and args.kernel_table > 0:
+        L.check(lib.czc_prof_enable(1))
+        for i in range(args.kernel_table):
+            step(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        kernels = kernel_table(L.prof_report(), args.kernel_table)
+        L.check(lib.czc_prof_enable(0))
+    elif args.kernel_table > 0:
+        for i in range(args.kernel_table):     # the other ranks take the same collectives
+            step(args.warmup + args.steps + i)
+
     if rank == 0:
         log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
         pairs = args.batch * world * args.steps
         value = pairs / elapsed
         kern_ms = tot_ms.value / max(1, cnt.value)
         kern_tflops = (2.0 * M * N * K) / (kern_ms * 1e-3) / 1e12 if cnt.value else None
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_pmc_ffn_up.json")
+        # HBM bytes of the roofline kernel come from separate rocprofv3 --pmc passes (tools/pmc_ffn_up.py); the file names
+        # the commit of gemm_bf16.hip it was collected on, and a figure collected on another version of the kernel is
+        # reported as null rather than passed off as current
+        traffic, traffic_note = None, None
+        tpath = os.path.join(ROOT, "profiles", "r2_pmc_ffn_up.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+                pmc = json.load(f)
+            import hashlib
+            with open(os.path.join(ROOT, "czech_contriever_amd", "csrc", "gemm_bf16.hip"), "rb") as f:
+                now = hashlib.sha1(f.read()).hexdigest()
+            if pmc.get("gemm_bf16_sha1") == now:
+                traffic = pmc.get("hbm_bytes_per_launch")
+            traffic_note = (f"rocprofv3 --pmc passes of commit {pmc.get('commit')}, gemm_bf16.hip sha1 {pmc.get('gemm_bf16_sha1')}"
+                            + ("" if traffic is not None else f" -- STALE (kernel source is now {now}): not reported"))
         headline = (args.batch == 256 and args.seq == 256 and args.queue == 131072 and not args.no_dropout
                     and args.objective == "moco" and not args.ragged)
         # in-batch: q fwd+bwd and k fwd+bwd = 6 encoder forwards' worth (275.4 G) + a 2*B*W*B*768 score product
@@ -379,7 +445,11 @@ def main():
                          "traffic": traffic,
                          "kernel": "czc::gemm_kernel<0,0,2> FFN-up x.W1^T + bias -> (u, gelu(u)), "
                                    f"M={M} N={N} K={K}, {2.0 * M * N * K / 1e9:.1f} GFLOP/launch",
-                         "kernel_ms": round(kern_ms, 4), "launches_timed": cnt.value,
+                         "kernel_ms": round(kern_ms, 4), "launches_timed": cnt.value, "traffic_source": traffic_note,
+                         "kernel_choice": "the largest single GEMM shape below its siblings' rate (FFN-up with its two-output "
+                                          "GELU epilogue); by time the largest operations are the ones listed first in `kernels`",
+                         "kernels": None if kernels is None else kernels[:8],
+                         "hbm_kernels": None if kernels is None else [k for k in kernels if k["bound"] == "hbm"][:10],
                          "whole_step_frac": None if args.ragged else round(value * flop_per_pair / (world * PEAK_BF16_TFLOPS * 1e12), 4)},
             "final_loss": round(float(last.detach()), 4),
         }

@@ -982,6 +982,8 @@ extern "C" int czc_attention_forward(const uint16_t* qkv, const uint8_t* mask, i
                                      float dropout_p, uint32_t seed, uint32_t site, uint16_t* ctx, float* lse,
                                      czc_stream_t stream) {
   if (int rc = attn_check("czc_attention_forward", batch, seq, heads, dropout_p)) return rc;
+  ProfScope prof((hipStream_t)stream, "attention_fwd", 4.0 * seq * (double)seq * 64.0 * heads * batch,
+                 2.0 * batch * (double)seq * heads * 64.0 * 4.0);
   AttnArgs a{};
   a.qkv = qkv; a.mask = mask; a.out = ctx; a.lse = lse;
   a.B = batch; a.S = seq; a.nh = heads; a.H = heads * 64;
@@ -1006,6 +1008,8 @@ extern "C" int czc_attention_backward(const uint16_t* qkv, const uint8_t* mask, 
                                       float dropout_p, uint32_t seed, uint32_t site, float* delta, uint16_t* dqkv,
                                       float* d_bias_qkv, float* partials, czc_stream_t stream) {
   if (int rc = attn_check("czc_attention_backward", batch, seq, heads, dropout_p)) return rc;
+  ProfScope prof((hipStream_t)stream, "attention_bwd", 10.0 * seq * (double)seq * 64.0 * heads * batch,
+                 2.0 * batch * (double)seq * heads * 64.0 * 8.0);
   AttnArgs a{};
   a.qkv = qkv; a.mask = mask; a.ctx = ctx; a.dctx = dctx; a.lse_in = lse; a.delta = delta; a.dqkv = dqkv; a.dbias = d_bias_qkv ? partials : nullptr;
   CZC_REQUIRE(!d_bias_qkv || partials, "czc_attention_backward: d_bias_qkv needs the partials scratch");

@@ -36,6 +36,21 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 #define CZC_LAUNCH_CHECK() CZC_HIP(hipGetLastError())
 
+// ---- per-operation timing (czc_prof_enable / czc_prof_read, include/czc.h) -------------------------
+// A scope around an operation's launches records a hipEvent pair on the launch stream while profiling is on and costs
+// one predictable branch while it is off.  `flops` / `bytes` are the ALGORITHMIC work of the operation (what
+// DESIGN.md prices it at), so the reader can turn the measured time into TFLOP/s or GB/s.
+extern bool g_prof_on;
+int prof_begin(hipStream_t st, const char* name, double flops, double bytes);
+void prof_end(hipStream_t st, int handle);
+struct ProfScope {
+  hipStream_t st;
+  int h;
+  ProfScope(hipStream_t s, const char* name, double flops = 0.0, double bytes = 0.0)
+      : st(s), h(g_prof_on ? prof_begin(s, name, flops, bytes) : -1) {}
+  ~ProfScope() { if (h >= 0) prof_end(st, h); }
+};
+
 // ---- bf16 <-> f32 --------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {

@@ -228,7 +228,8 @@ extern "C" int64_t czc_encoder_backward_scratch_bytes(const czc_bert_shape* s, i
 extern "C" int czc_encoder_forward(const czc_bert_shape* s, const float* params_f32, const uint16_t* params_bf16,
                                    const int64_t* ids, const uint8_t* mask, int batch, int seq, int pooling,
                                    int normalize, int training, uint32_t seed, int save_for_backward, void* workspace,
-                                   int64_t workspace_bytes, float* emb_out, czc_stream_t stream) {
+                                   int64_t workspace_bytes, float* emb_out, int split_batch, void* split_event,
+                                   czc_stream_t stream) {
   RC(shape_check("czc_encoder_forward", s));
   CZC_REQUIRE(batch > 0 && seq > 0 && seq <= s->max_position && seq <= 512, "czc_encoder_forward: batch=%d seq=%d (max_position=%d, <= 512)", batch, seq, s->max_position);
   CZC_REQUIRE(s->num_layers <= 64, "czc_encoder_forward: at most 64 layers");
@@ -250,25 +251,54 @@ extern "C" int czc_encoder_forward(const czc_bert_shape* s, const float* params_
 #define BUF(off) ((uint16_t*)(ws + (off)))
 #define FBUF(off) ((float*)(ws + (off)))
 
+  CZC_REQUIRE(split_batch >= 0 && split_batch < batch, "czc_encoder_forward: split_batch=%d outside [0, %d)", split_batch, batch);
+  CZC_REQUIRE(split_batch == 0 || !save_for_backward,
+              "czc_encoder_forward: the split last layer is for passes nothing differentiates through (the key encoder)");
   RC(czc_embed_ln_forward(ids, batch, seq, H, s->vocab_size, PF(CZC_P_WORD, 0), PF(CZC_P_POS, 0), PF(CZC_P_TYPE, 0),
                           PF(CZC_P_ELNW, 0), PF(CZC_P_ELNB, 0), s->layer_norm_eps, ph, seed, SITE_EMB, BUF(e.x[0]),
                           FBUF(e.st0), stream));
-  for (int l = 0; l < L; ++l) {
+  // layer l on sequences [b0, b0 + nb): every buffer is token-major, so a batch range is a row offset.  `sh` shifts the
+  // dropout sites of a second range so that its masks are not those of the first (the draws are indexed from the
+  // start of each launch's rows)
+  auto layer = [&](int l, int b0, int nb, unsigned sh) -> int {
     const LayerWs& w = e.layer[l];
-    RC(gemm(0, 0, EPI_BIAS, M, 3 * H, H, BUF(e.x[l]), H, WB(CZC_P_WQKV, l), H, BUF(w.qkv), 3 * H, PF(CZC_P_BQKV, l), nullptr, nullptr, 1, st));
-    RC(czc_attention_forward(BUF(w.qkv), mask, batch, seq, nh, pa, seed, SITE_ATTN(l), BUF(w.ctx), FBUF(w.lse), stream));
-    RC(gemm(0, 0, EPI_BIAS, M, H, H, BUF(w.ctx), H, WB(CZC_P_WO, l), H, BUF(w.y1), H, PF(CZC_P_BO, l), nullptr, nullptr, 1, st));
-    RC(czc_residual_ln_forward(BUF(w.y1), BUF(e.x[l]), M, H, PF(CZC_P_LN1W, l), PF(CZC_P_LN1B, l), s->layer_norm_eps, ph,
-                               seed, SITE_H1(l), BUF(w.x1), FBUF(w.st1), stream));
+    const int Mr = nb * seq;
+    const int64_t r0 = (int64_t)b0 * seq;
+    uint16_t* x = BUF(e.x[l]) + r0 * H;
+    uint16_t* qkv = BUF(w.qkv) + r0 * 3 * H; uint16_t* ctx = BUF(w.ctx) + r0 * H;
+    uint16_t* y1 = BUF(w.y1) + r0 * H; uint16_t* x1 = BUF(w.x1) + r0 * H;
+    uint16_t* u = BUF(w.u) + r0 * I; uint16_t* hact = BUF(w.hact) + r0 * I; uint16_t* y2 = BUF(w.y2) + r0 * H;
+    RC(gemm(0, 0, EPI_BIAS, Mr, 3 * H, H, x, H, WB(CZC_P_WQKV, l), H, qkv, 3 * H, PF(CZC_P_BQKV, l), nullptr, nullptr, 1, st));
+    RC(czc_attention_forward(qkv, mask + r0, nb, seq, nh, pa, seed, SITE_ATTN(l) + sh, ctx, FBUF(w.lse) + (int64_t)b0 * nh * seq, stream));
+    RC(gemm(0, 0, EPI_BIAS, Mr, H, H, ctx, H, WB(CZC_P_WO, l), H, y1, H, PF(CZC_P_BO, l), nullptr, nullptr, 1, st));
+    RC(czc_residual_ln_forward(y1, x, Mr, H, PF(CZC_P_LN1W, l), PF(CZC_P_LN1B, l), s->layer_norm_eps, ph,
+                               seed, SITE_H1(l) + sh, x1, FBUF(w.st1) + r0 * 2, stream));
     if (save_for_backward)
-      RC(gemm(0, 0, EPI_BIAS_GELU, M, I, H, BUF(w.x1), H, WB(CZC_P_W1, l), H, BUF(w.u), I, PF(CZC_P_B1, l), nullptr, BUF(w.hact), 1, st));
+      RC(gemm(0, 0, EPI_BIAS_GELU, Mr, I, H, x1, H, WB(CZC_P_W1, l), H, u, I, PF(CZC_P_B1, l), nullptr, hact, 1, st));
     else   // nothing differentiates through this pass (key encoder, inference): keep gelu(u) only
-      RC(gemm(0, 0, EPI_BIAS_GELU1, M, I, H, BUF(w.x1), H, WB(CZC_P_W1, l), H, BUF(w.hact), I, PF(CZC_P_B1, l), nullptr, nullptr, 1, st));
-    RC(gemm(0, 0, EPI_BIAS, M, H, I, BUF(w.hact), I, WB(CZC_P_W2, l), I, BUF(w.y2), H, PF(CZC_P_B2, l), nullptr, nullptr, 1, st));
-    RC(czc_residual_ln_forward(BUF(w.y2), BUF(w.x1), M, H, PF(CZC_P_LN2W, l), PF(CZC_P_LN2B, l), s->layer_norm_eps, ph,
-                               seed, SITE_H2(l), BUF(e.x[l + 1]), FBUF(w.st2), stream));
+      RC(gemm(0, 0, EPI_BIAS_GELU1, Mr, I, H, x1, H, WB(CZC_P_W1, l), H, hact, I, PF(CZC_P_B1, l), nullptr, nullptr, 1, st));
+    RC(gemm(0, 0, EPI_BIAS, Mr, H, I, hact, I, WB(CZC_P_W2, l), I, y2, H, PF(CZC_P_B2, l), nullptr, nullptr, 1, st));
+    RC(czc_residual_ln_forward(y2, x1, Mr, H, PF(CZC_P_LN2W, l), PF(CZC_P_LN2B, l), s->layer_norm_eps, ph,
+                               seed, SITE_H2(l) + sh, BUF(e.x[l + 1]) + r0 * H, FBUF(w.st2) + r0 * 2, stream));
+    return CZC_OK;
+  };
+  auto pool = [&](int b0, int nb) -> int {
+    return czc_pool_forward(BUF(e.x[L]) + (int64_t)b0 * seq * H, mask + (int64_t)b0 * seq, nb, seq, H, pooling, normalize,
+                            emb_out + (int64_t)b0 * H, FBUF(e.raw) + (int64_t)b0 * H, stream);
+  };
+  for (int l = 0; l < L - (split_batch ? 1 : 0); ++l) RC(layer(l, 0, batch, 0u));
+  if (split_batch) {
+    // The last layer and the pooling in two batch ranges: the embeddings of sequences [0, split_batch) are complete
+    // -- `split_event` is recorded behind them -- while the rest of the batch is still being encoded, so the caller's
+    // side stream can start their all-gather under this call's tail (src/moco.py, the key encoder under data parallelism)
+    RC(layer(L - 1, 0, split_batch, 0u));
+    RC(pool(0, split_batch));
+    if (split_event) CZC_HIP(hipEventRecord((hipEvent_t)split_event, st));
+    RC(layer(L - 1, split_batch, batch - split_batch, 4u));
+    RC(pool(split_batch, batch - split_batch));
+  } else {
+    RC(pool(0, batch));
   }
-  RC(czc_pool_forward(BUF(e.x[L]), mask, batch, seq, H, pooling, normalize, emb_out, FBUF(e.raw), stream));
   return CZC_OK;
 }
 

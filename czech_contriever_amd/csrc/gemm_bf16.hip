@@ -924,6 +924,13 @@ int gemm_dispatch(int al, int bl, int epi, GemmArgs a, int splitk, hipStream_t s
   const bool hit = p.armed && p.count < p.max_samples && al == p.al && bl == p.bl && epi == p.epi && a.M == p.M &&
                    a.N == p.N && a.K == p.K;
   if (hit) CZC_HIP(hipEventRecord(p.ev[2 * p.count], st));
+  char pname[96];
+  if (g_prof_on) snprintf(pname, sizeof(pname), "gemm a%d b%d epi%d %dx%dx%d%s", al, bl, epi, a.M, a.N, a.K, splitk > 1 ? " splitk" : "");
+  const double outb = (epi == EPI_F32 ? 4.0 * splitk : (epi == EPI_LSE || epi == EPI_FILTER) ? 0.0 : 2.0) *
+                      (epi == EPI_BIAS_GELU ? 2.0 : 1.0);
+  ProfScope prof(st, g_prof_on ? pname : "", 2.0 * a.M * (double)a.N * a.K,
+                 2.0 * ((double)a.M * a.K + (double)a.N * a.K) + outb * a.M * (double)a.N +
+                     ((epi == EPI_DGELU || epi == EPI_ADD) ? 2.0 * a.M * (double)a.N : 0.0));
   const int rc = gemm_dispatch_inner(al, bl, epi, a, splitk, st);
   if (hit) {
     CZC_HIP(hipEventRecord(p.ev[2 * p.count + 1], st));
@@ -1047,6 +1054,7 @@ extern "C" int czc_probe_read(float* total_ms, int* count) {
 extern "C" int czc_reduce_slabs(const float* slabs, int nslabs, int64_t n, float* dst, int accumulate,
                                 czc_stream_t stream) {
   CZC_REQUIRE(n % 4 == 0 && nslabs >= 1, "czc_reduce_slabs: n=%lld must be a multiple of 4", (long long)n);
+  ProfScope prof((hipStream_t)stream, "reduce_slabs", 0.0, 4.0 * n * (nslabs + 1 + (accumulate ? 1 : 0)));
   const int64_t n4 = n / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 4096) blocks = 4096;

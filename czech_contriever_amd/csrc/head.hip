@@ -55,12 +55,17 @@ __global__ __launch_bounds__(256) void head_final_kernel(const float* __restrict
   se = wave_sum(se);
   sm = wave_sum(sm);
   if (lane != 0) return;
-  const float z0 = lpos[b] * invT;
+  // the positive logit as ONE rounded fp32 value, as the reference's `logits / T` tensor holds it (__fmul_rn: never fused
+  // into the subtractions below).  With `lpos * invT` the compiler contracted `lse - z0` into fma(-lpos, invT, lse), i.e.
+  // subtracted the UNROUNDED product: when the positive dominates (lse == z0; every early step with the README flags)
+  // loss and coefficient came out as the product's rounding residual instead of exactly 0, and AdamW -- which
+  // normalises any non-zero gradient to a full-size step -- moved every weight by lr along that noise.
+  const float z0 = __fmul_rn(lpos[b], invT);
   const float M = fmaxf(mx, z0);
   const float tot = se * __expf(mx - M) + __expf(z0 - M);
   const float lse = M + __logf(tot);
   lse_out[b] = lse;
-  rowloss[b] = (1.0f - ls) * (lse - z0) + ls * (lse - (sm + z0) / (float)(Kq + 1));
+  rowloss[b] = (1.0f - ls) * __fsub_rn(lse, z0) + ls * (lse - (sm + z0) / (float)(Kq + 1));
   rowok[b] = (z0 >= mx) ? 1.0f : 0.f;   // argmax picks column 0 on ties, as torch.argmax does
 }
 
@@ -115,8 +120,8 @@ __global__ __launch_bounds__(256) void head_bwd_final_kernel(const float* __rest
   const int b = (int)((i * 4) / C);
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   for (int z = 0; z < nslabs; ++z) s += ((const f32x4*)slabs)[(int64_t)z * n4 + i];
-  const float z0 = lpos[b] * invT;
-  const float coef0 = __expf(z0 - lse[b]) - (1.0f - ls) - ls / (float)(Kq + 1);
+  const float z0 = __fmul_rn(lpos[b], invT);   // the same rounded value head_final_kernel folded into lse (see there)
+  const float coef0 = __expf(__fsub_rn(z0, lse[b])) - (1.0f - ls) - ls / (float)(Kq + 1);
   ((f32x4*)dq)[i] = (s + ((const f32x4*)k)[i] * coef0) * scale;
 }
 
@@ -209,6 +214,7 @@ extern "C" int czc_infonce_forward(const float* q, const float* k, const uint16_
                                    int queue_size, float temperature, float label_smoothing, void* workspace,
                                    int64_t workspace_bytes, float* lse_out, float* stats_out, czc_stream_t stream) {
   if (int rc = head_check("czc_infonce_forward", batch, dim, queue_size, temperature, label_smoothing, workspace, workspace_bytes)) return rc;
+  ProfScope prof((hipStream_t)stream, "infonce_fwd", 2.0 * batch * (double)dim * (queue_size + 1), 2.0 * queue_size * (double)dim);
   hipStream_t st = (hipStream_t)stream;
   const HeadWs w = head_ws(batch, dim, queue_size);
   char* base = (char*)workspace;
@@ -238,6 +244,7 @@ extern "C" int czc_infonce_backward(const float* q, const float* k, const uint16
                                     czc_stream_t stream) {
   if (int rc = head_check("czc_infonce_backward", batch, dim, queue_size, temperature, label_smoothing, workspace, workspace_bytes)) return rc;
   CZC_REQUIRE(((int64_t)batch * dim) % 4 == 0, "czc_infonce_backward: batch*dim must be a multiple of 4");
+  ProfScope prof((hipStream_t)stream, "infonce_bwd", 4.0 * batch * (double)dim * queue_size, 4.0 * queue_size * (double)dim + 4.0 * batch * (double)queue_size);
   hipStream_t st = (hipStream_t)stream;
   const HeadWs w = head_ws(batch, dim, queue_size);
   char* base = (char*)workspace;
@@ -267,6 +274,7 @@ extern "C" int czc_enqueue(const float* keys, int n, int dim, int queue_size, ui
                            int64_t* queue_ptr, czc_stream_t stream) {
   CZC_REQUIRE(n > 0 && dim > 0 && queue_size > 0 && n <= queue_size, "czc_enqueue: n=%d dim=%d queue=%d", n, dim, queue_size);
   CZC_REQUIRE(queue_size % n == 0, "czc_enqueue: %d, %d (queue_size must be divisible by the gathered batch)", n, queue_size);
+  ProfScope prof((hipStream_t)stream, "enqueue", 0.0, (double)n * dim * (4.0 + 2.0 + (queue_f32 ? 4.0 : 0.0)));
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(enqueue_kernel, dim3(ceil_div(n, 64), ceil_div(dim, 64)), dim3(256), 0, st, keys, n, dim,
                      queue_size, queue_bf16, queue_f32, queue_ptr);

@@ -131,6 +131,7 @@ extern "C" int czc_ema_update(float* pk, const float* pq, int64_t n, float m, fl
   CZC_REQUIRE(n > 0 && n_bf16 >= 0 && n_bf16 <= n && (n_bf16 % 4) == 0, "czc_ema_update: n=%lld n_bf16=%lld",
               (long long)n, (long long)n_bf16);
   CZC_REQUIRE(((uintptr_t)pk % 16) == 0 && ((uintptr_t)pq % 16) == 0, "czc_ema_update: arrays must be 16-byte aligned");
+  ProfScope prof((hipStream_t)stream, "ema", 0.0, 12.0 * n + 2.0 * (pk_bf16 ? n_bf16 : 0));
   hipLaunchKernelGGL(ema_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, pk, pq, n / 4, n, m,
                      one_minus_m, pk_bf16, pk_bf16 ? n_bf16 : 0);
   CZC_LAUNCH_CHECK();
@@ -144,6 +145,7 @@ extern "C" int czc_adamw_step(float* p, const float* g, float* m, float* v, int6
               "czc_adamw_step: n=%lld step=%d n_bf16=%lld", (long long)n, step, (long long)n_bf16);
   CZC_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
               "czc_adamw_step: arrays must be 16-byte aligned");
+  ProfScope prof((hipStream_t)stream, "adamw", 0.0, 28.0 * n + 2.0 * (p_bf16 ? n_bf16 : 0));
   AdamArgs a;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);

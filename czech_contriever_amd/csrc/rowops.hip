@@ -529,6 +529,7 @@ extern "C" int czc_residual_ln_forward(const uint16_t* y, const uint16_t* resid,
                                        uint32_t seed, uint32_t site, uint16_t* x, float* stats, czc_stream_t stream) {
   CZC_REQUIRE(hidden_ok(hidden), "czc_residual_ln_forward: hidden=%d must be a multiple of 8 and <= 1024", hidden);
   CZC_REQUIRE(rows > 0 && dropout_p >= 0.f && dropout_p < 1.f, "czc_residual_ln_forward: rows=%d p=%f", rows, dropout_p);
+  ProfScope prof((hipStream_t)stream, "residual_ln_fwd", 0.0, 2.0 * rows * (double)hidden * 3.0 + 8.0 * rows);
   DROP_ARGS(dropout_p);
   LAUNCH_NIT(residual_ln_fwd_kernel, hidden, dim3(row_grid(rows)), (hipStream_t)stream, y, resid, rows, hidden, gamma, beta,
              eps, thr, inv_keep, seed, site, x, stats);
@@ -545,6 +546,8 @@ extern "C" int czc_residual_ln_backward(const uint16_t* dx, const uint16_t* dx2,
   CZC_REQUIRE(rows > 0 && dropout_p >= 0.f && dropout_p < 1.f, "czc_residual_ln_backward: rows=%d p=%f", rows, dropout_p);
   CZC_REQUIRE(dz_out && dy_out, "czc_residual_ln_backward: outputs missing");
   CZC_REQUIRE(!(dropout_p > 0.f && dz_out == dy_out), "czc_residual_ln_backward: dy_out must differ from dz_out when p > 0");
+  ProfScope prof((hipStream_t)stream, "residual_ln_bwd", 0.0,
+                 2.0 * rows * (double)hidden * (3.0 + (dx2 ? 1.0 : 0.0) + 1.0 + (dropout_p > 0.f ? 1.0 : 0.0)) + 8.0 * rows);
   DROP_ARGS(dropout_p);
   // 119 VGPRs -> 4 workgroups per CU are resident: exactly one round of 1024 (measured: 2048 -> 206 us, 1024 -> 155 us,
   // 512 -> 200 us at 65536 x 768)
@@ -563,6 +566,7 @@ extern "C" int czc_embed_ln_forward(const int64_t* ids, int batch, int seq, int 
                                     float* stats, czc_stream_t stream) {
   CZC_REQUIRE(hidden_ok(hidden), "czc_embed_ln_forward: hidden=%d must be a multiple of 8 and <= 1024", hidden);
   CZC_REQUIRE(batch > 0 && seq > 0 && vocab > 0, "czc_embed_ln_forward: batch=%d seq=%d vocab=%d", batch, seq, vocab);
+  ProfScope prof((hipStream_t)stream, "embed_ln_fwd", 0.0, (double)batch * seq * hidden * (4.0 + 2.0) + 8.0 * batch * seq);
   DROP_ARGS(dropout_p);
   const int rows = batch * seq;
   LAUNCH_NIT(embed_ln_fwd_kernel, hidden, dim3(row_grid(rows)), (hipStream_t)stream, ids, rows, seq, hidden, vocab, word, pos,
@@ -578,6 +582,7 @@ extern "C" int czc_embed_ln_backward(const int64_t* ids, int batch, int seq, int
                                      czc_stream_t stream) {
   CZC_REQUIRE(hidden_ok(hidden), "czc_embed_ln_backward: hidden=%d must be a multiple of 8 and <= 1024", hidden);
   CZC_REQUIRE(batch > 0 && seq > 0 && vocab > 0, "czc_embed_ln_backward: batch=%d seq=%d vocab=%d", batch, seq, vocab);
+  ProfScope prof((hipStream_t)stream, "embed_ln_bwd", 0.0, (double)batch * seq * hidden * (4.0 + 2.0 + 4.0) + 8.0 * batch * seq);
   DROP_ARGS(dropout_p);
   const int rows = batch * seq;
   int g = row_grid(rows);
@@ -594,6 +599,7 @@ extern "C" int czc_pool_forward(const uint16_t* x, const uint8_t* mask, int batc
   CZC_REQUIRE(hidden_ok(hidden), "czc_pool_forward: hidden=%d must be a multiple of 8 and <= 1024", hidden);
   CZC_REQUIRE(batch > 0 && seq > 0 && seq <= 512, "czc_pool_forward: batch=%d seq=%d (seq <= 512)", batch, seq);
   CZC_REQUIRE(pooling == CZC_POOL_AVERAGE || pooling == CZC_POOL_CLS, "czc_pool_forward: pooling=%d", pooling);
+  ProfScope prof((hipStream_t)stream, "pool_fwd", 0.0, 2.0 * batch * (double)seq * hidden);
   hipLaunchKernelGGL(pool_fwd_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, x, mask, seq, hidden, pooling,
                      normalize, emb, raw_out);
   CZC_LAUNCH_CHECK();
@@ -605,6 +611,7 @@ extern "C" int czc_pool_backward(const float* d_emb, const float* raw, const uin
   CZC_REQUIRE(hidden_ok(hidden), "czc_pool_backward: hidden=%d must be a multiple of 8 and <= 1024", hidden);
   CZC_REQUIRE(batch > 0 && seq > 0 && seq <= 512, "czc_pool_backward: batch=%d seq=%d (seq <= 512)", batch, seq);
   CZC_REQUIRE(!normalize || raw, "czc_pool_backward: normalize needs the raw embedding");
+  ProfScope prof((hipStream_t)stream, "pool_bwd", 0.0, 2.0 * batch * (double)seq * hidden);
   hipLaunchKernelGGL(pool_bwd_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, d_emb, raw, mask, seq, hidden,
                      pooling, normalize, dx);
   CZC_LAUNCH_CHECK();
@@ -616,6 +623,7 @@ extern "C" int64_t czc_colsum_scratch_floats(int hidden) { return (int64_t)2048 
 extern "C" int czc_reduce_partials(const float* partials, int nrows, int row_stride, int ncols, float* dst,
                                    czc_stream_t stream) {
   CZC_REQUIRE(partials && dst && nrows > 0 && ncols > 0 && row_stride >= ncols, "czc_reduce_partials: bad arguments");
+  ProfScope prof((hipStream_t)stream, "reduce_partials", 0.0, 4.0 * nrows * (double)ncols);
   launch_reduce_partials(partials, nrows, row_stride, ncols, dst, (hipStream_t)stream);
   CZC_LAUNCH_CHECK();
   return CZC_OK;

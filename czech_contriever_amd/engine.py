@@ -72,6 +72,9 @@ def _numel(shape):
 class FlatBertEncoder(nn.Module):
     """BERT encoder + pooling whose arithmetic runs in libczc.so.  Subclassed by src.contriever.Contriever."""
 
+    _instances = 0          # every encoder of the process gets its own dropout salt, in construction order
+    _skip_init = False      # set around the constructor call of __deepcopy__: the copy's weights are overwritten anyway
+
     def __init__(self, config, pooling: str = "average"):
         super().__init__()
         self.config = config
@@ -100,7 +103,10 @@ class FlatBertEncoder(nn.Module):
         self._ws_pool: Dict[tuple, list] = {}
         self._scratch = None
         self._call = 0
+        self._salt = FlatBertEncoder._instances   # deterministic per process: encoder_q 0, its key copy 1, ...
+        FlatBertEncoder._instances += 1
         self._anchor = None
+        self._pre_grad_access = []  # callables() run before the main stream touches the flat gradient array (comm wait)
         self._post_backward = []  # callables(enc) run right after the backward has been enqueued
         self._range_hooks = []    # callables(enc, elem_lo, elem_hi): a gradient range [lo, hi) of the flat array is final
         self.backward_chunk_layers = 0   # > 0: issue the backward in ranges of this many layers (for comm overlap)
@@ -115,7 +121,9 @@ class FlatBertEncoder(nn.Module):
             prm = nn.Parameter(self._flat[off:off + _numel(shape)].view(shape))
             node.register_parameter(parts[-1], prm)
             self._plist.append(prm)
-        self.reset_parameters()
+        if not FlatBertEncoder._skip_init:
+            self.reset_parameters()
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_mirror())
 
     # ---- initialisation: HF BertPreTrainedModel._init_weights (N(0, initializer_range); LN = 1, 0) ----
     def reset_parameters(self):
@@ -128,6 +136,7 @@ class FlatBertEncoder(nn.Module):
                     p.zero_()
                 else:
                     p.normal_(mean=0.0, std=std)
+        self.invalidate_mirror()
 
     # ---- storage management ----------------------------------------------------------------------
     def _rebind(self):
@@ -151,13 +160,17 @@ class FlatBertEncoder(nn.Module):
                 self._ws_pool.clear()
                 self._scratch = None
                 self._anchor = None
-            self._mirror_version = -1
             self._rebind()
+            self.invalidate_mirror()
         return self
 
     def __deepcopy__(self, memo):
         import copy
-        new = self.__class__(copy.deepcopy(self.config, memo))
+        FlatBertEncoder._skip_init = True     # no random init of the copy: it would consume the torch RNG the reference
+        try:                                  # draws the initial queue from right after copy.deepcopy (src/moco.py:209-219)
+            new = self.__class__(copy.deepcopy(self.config, memo))
+        finally:
+            FlatBertEncoder._skip_init = False
         new.to(self._flat.device)
         with torch.no_grad():
             new._flat.copy_(self._flat)
@@ -180,6 +193,16 @@ class FlatBertEncoder(nn.Module):
             self._flat_grad = torch.zeros_like(self._flat)
         return self._flat_grad
 
+    def _write_stamp(self) -> int:
+        """Changes whenever torch wrote the weights in place: through the flat array or through any parameter view.  (After
+        .cuda() / .to() the parameters are re-pointed with `p.data = view`, which gives each its OWN version counter, so the
+        flat array's counter alone would miss load_state_dict / p.copy_() / a torch optimizer on a GPU-resident encoder.)"""
+        return self._flat._version + sum(p._version for p in self._plist)
+
+    def invalidate_mirror(self):
+        """Call after writing the fp32 weights by any means this class cannot see (raw pointers, custom kernels)."""
+        self._mirror_version = -1
+
     def mirror(self) -> torch.Tensor:
         """bf16 copy of the matrix region, refreshed when the fp32 array was written by torch."""
         if not self._flat.is_cuda:
@@ -187,14 +210,16 @@ class FlatBertEncoder(nn.Module):
         if self._mirror is None:
             self._mirror = torch.empty(self._n_mat, dtype=BF16, device=self._flat.device)
             self._mirror_version = -1
-        if self._mirror_version != self._flat._version:
+        stamp = self._write_stamp()
+        if self._mirror_version != stamp:
             L.check(L.load().czc_cast_bf16(self._flat.data_ptr(), self._mirror.data_ptr(), self._n_mat, L.stream_ptr()))
-            self._mirror_version = self._flat._version
+            self._mirror_version = stamp
             self._mirror_epoch += 1
         return self._mirror
 
     def mark_mirror_fresh(self):
-        self._mirror_version = self._flat._version
+        """libczc itself rewrote the weights AND the mirror in one pass (AdamW, the momentum EMA)."""
+        self._mirror_version = self._write_stamp()
         self._mirror_epoch += 1
 
     def mirror_t(self):
@@ -278,7 +303,9 @@ class FlatBertEncoder(nn.Module):
         return self._shape
 
     # ---- compute -----------------------------------------------------------------------------------
-    def encode(self, input_ids, attention_mask, normalize=False):
+    def encode(self, input_ids, attention_mask, normalize=False, split=None):
+        """split = (n, event): passes that nothing differentiates through may run the last layer + pooling in two batch
+        ranges and record the czc event once the first n embeddings are complete (czc_encoder_forward, include/czc.h)."""
         if input_ids.dim() != 2:
             raise ValueError("input_ids must be [batch, seq]")
         if not input_ids.is_cuda:
@@ -290,23 +317,27 @@ class FlatBertEncoder(nn.Module):
             if self._anchor is None or self._anchor.device != self._flat.device:
                 self._anchor = torch.zeros(1, device=self._flat.device, requires_grad=True)
             return _EncoderFn.apply(self._anchor, self, ids, mask, bool(normalize))
-        return self._forward_impl(ids, mask, bool(normalize), save=False)[0]
+        return self._forward_impl(ids, mask, bool(normalize), save=False, split=split)[0]
 
-    def _forward_impl(self, ids, mask, normalize, save):
+    def _forward_impl(self, ids, mask, normalize, save, split=None):
         B, S = ids.shape
         self._call += 1
         ws = self._lease_activations(B, S, self._call) if save else self._workspace(B, S, False)
         emb = torch.empty(B, self.config.hidden_size, dtype=F32, device=ids.device)
-        seed = (torch.initial_seed() * 2654435761 + self._call * 40503 + id(self) % 9973) & 0xFFFFFFFF
+        # (--seed, encoder, call): the same run draws the same masks; query and key encoder never share a stream of draws
+        seed = (torch.initial_seed() * 2654435761 + self._call * 40503 + (self._salt + 1) * 0x9E3779B1) & 0xFFFFFFFF
+        n_split, ev = (0, None) if (split is None or save) else (int(split[0]), split[1])
         L.check(L.load().czc_encoder_forward(
             C.byref(self._shape), self._flat.data_ptr(), self.mirror().data_ptr(), ids.data_ptr(), mask.data_ptr(),
             B, S, self._pool_code(), int(normalize), int(self.training), seed, int(save), ws.data_ptr(), ws.numel(),
-            emb.data_ptr(), L.stream_ptr()))
+            emb.data_ptr(), n_split, ev, L.stream_ptr()))
         return emb, seed, ws
 
     def _backward_impl(self, ids, mask, normalize, seed, ws, d_emb, training):
         B, S = ids.shape
         sc = self._bwd_scratch(B, S)
+        for hook in self._pre_grad_access:   # a gradient all-reduce of an earlier backward may still be averaging the array
+            hook()
         fresh = any(p.grad is None for p in self._plist if p.requires_grad)
         g = self.flat_grads()
         nl = self._shape.num_layers

@@ -35,7 +35,11 @@ SIGNATURES = {
     "czc_param_offset": (i64, [SP, i32, i32]),
     "czc_encoder_workspace_bytes": (i64, [SP, i32, i32, i32]),
     "czc_encoder_backward_scratch_bytes": (i64, [SP, i32, i32]),
-    "czc_encoder_forward": (i32, [SP, vp, vp, vp, vp, i32, i32, i32, i32, i32, u32, i32, vp, i64, vp, vp]),
+    "czc_encoder_forward": (i32, [SP, vp, vp, vp, vp, i32, i32, i32, i32, i32, u32, i32, vp, i64, vp, i32, vp, vp]),
+    "czc_event_create": (i32, [C.POINTER(vp)]),
+    "czc_event_destroy": (i32, [vp]),
+    "czc_event_record": (i32, [vp, vp]),
+    "czc_stream_wait_event": (i32, [vp, vp]),
     "czc_encoder_backward": (i32, [SP, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, u32, vp, i64, vp, i64, vp, vp, i32, i32, i32, vp]),
     "czc_transpose_matrices": (i32, [SP, vp, vp, vp]),
     "czc_infonce_workspace_bytes": (i64, [i32, i32, i32]),
@@ -53,6 +57,8 @@ SIGNATURES = {
     "czc_gemm_set_tile": (i32, [i32]),
     "czc_probe_arm": (i32, [i32, i32, i32, i32, i32, i32, i32]),
     "czc_probe_read": (i32, [C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "czc_prof_enable": (i32, [i32]),
+    "czc_prof_read": (i64, [C.c_char_p, i64]),
     "czc_reduce_slabs": (i32, [vp, i32, i64, vp, i32, vp]),
     "czc_attention_forward": (i32, [vp, vp, i32, i32, i32, f32, u32, u32, vp, vp, vp]),
     "czc_attention_backward": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32, u32, u32, vp, vp, vp, vp, vp]),
@@ -98,10 +104,23 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError = a symbol czc.h declares is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.czc_abi_version() != 2:
+    if lib.czc_abi_version() != 3:
         raise RuntimeError("libczc.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def prof_report():
+    """[(name, calls, total_ms, flops_per_call, bytes_per_call)] collected since czc_prof_enable(1)"""
+    lib = load()
+    n = int(lib.czc_prof_read(None, 0))
+    buf = C.create_string_buffer(n)
+    lib.czc_prof_read(buf, n)
+    rows = []
+    for line in buf.value.decode().splitlines():
+        name, calls, ms, fl, by = line.split("\t")
+        rows.append((name, int(calls), float(ms), float(fl), float(by)))
+    return rows
 
 
 def last_error() -> str:

@@ -78,6 +78,8 @@ class FusedAdamW(torch.optim.Optimizer):
     # ---- gradient clipping on the flat array (train.py:314-322) ----
     @torch.no_grad()
     def clip_grad_norm_(self, max_norm):
+        for fn in self._pre_step:      # the overlapped gradient all-reduce must have finished averaging what is measured here
+            fn()
         enc = self._encoders[0]
         g = enc.flat_grads(create=False)
         if g is None:
@@ -93,6 +95,8 @@ class FusedAdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def clip_grad_value_(self, value):
+        for fn in self._pre_step:
+            fn()
         for enc in self._encoders:
             g = enc.flat_grads(create=False)
             if g is not None:

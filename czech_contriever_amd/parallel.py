@@ -2,21 +2,32 @@
 
 Replaces torch DDP at train.py:483-488 of the reference.  DDP cannot be used here: parameter
 gradients are written by libczc straight into one flat fp32 array, not through autograd hooks.
-What this wrapper does instead, per micro-step:
-  * gradient mean all-reduce of the flat gradient array in 5 collectives on a side stream: the encoder
+Two exchanges per micro-step, both on side HIP streams:
+
+`DataParallel` -- gradient mean all-reduce of the flat gradient array in 5 collectives: the encoder
     backward is issued in ranges of 3 layers (top first); as soon as a range has been enqueued its weight-matrix
     gradients (one contiguous 85 MB slice of the flat array) are averaged while the next range computes; the
-    vectors + embeddings tail (96 MB) goes last.  The optimizer waits on the last event.  (The reference all-reduces on every micro-step as well:
-    it never enters no_sync(), train.py:263-266.)
-  * no buffer broadcast: DDP re-broadcasts `queue` (403 MB) from rank 0 on every forward; the
-    replicas are identical by construction (same gathered keys, same order), so nothing is sent.
-The key all-gather is in src.moco / src.dist_utils."""
+    vectors + embeddings tail (96 MB) goes last.  Anything that touches the flat gradients on the main stream afterwards
+    (the optimizer, clipping, an accumulating backward, the L2-from-init penalty) first waits for the communication
+    stream.  (The reference all-reduces on every micro-step as well: it never enters no_sync(), train.py:263-266.)
+    No buffer broadcast: DDP re-broadcasts `queue` (403 MB) from rank 0 on every forward; the replicas are identical
+    by construction (same gathered keys, same order), so nothing is sent.
+
+`KeyExchange` -- the key all-gather of MoCo._dequeue_and_enqueue (src/moco.py:272-287 via src/dist_utils.py:29-37)
+    and the enqueue behind it.  The key encoder runs its last layer in two batch halves (czc_encoder_forward,
+    split_batch): the first half's embeddings are gathered while the second half is still being encoded, the second
+    half's while the InfoNCE head runs; the rows are put in rank-major order (rank r's B keys in batch order, as
+    torch.cat(all_gather(...)) gives) so every replica enqueues the same rows in the same slots.  The enqueue waits for
+    this step's logits (they read the columns it overwrites) and the main stream waits for the enqueue before it goes on."""
 from __future__ import annotations
+
+import ctypes as C
 
 import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from . import lib as L
 from .engine import FlatBertEncoder
 
 
@@ -42,6 +53,115 @@ def average_(flat: torch.Tensor, group=None):
     return flat
 
 
+@torch.no_grad()
+def _all_gather_rows(out: torch.Tensor, x: torch.Tensor, group):
+    """out [W * n, C] <- every rank's x [n, C], rank order (device tensors under gloo are staged through the host)."""
+    if x.is_cuda and dist.get_backend(group) != "nccl":
+        host = torch.empty(out.shape, dtype=x.dtype)
+        dist.all_gather_into_tensor(host, x.detach().cpu().contiguous(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+    return out
+
+
+class KeyExchange:
+    """Rank-order all-gather of a replica's key embeddings in (up to) two batch ranges, off the main stream.
+
+        kx = KeyExchange(group)
+        n = kx.split_for(B, S)                       # 0: no split (odd batch, one sequence, unaligned rows)
+        k = encoder_k.encode(..., split=(n, kx.split_event))
+        kx.gather(k, n)                              # side stream: rows [0, n) as soon as the event fires, then the rest
+        ... InfoNCE head on the main stream ...
+        kx.enqueue(fn)                               # side stream: after the head, fn(gathered [W * B, C]); main waits
+
+    Host tensors (the gloo tests) take the same path without streams."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = world(group)
+        self.stream = None
+        self.split_event = self.keys_event = self.head_event = self.done_event = None
+        self._bufs = {}
+        self.gathered = None
+
+    def _events(self):
+        if self.split_event is None:
+            lib = L.load()
+            evs = []
+            for _ in range(4):
+                e = C.c_void_p()
+                L.check(lib.czc_event_create(C.byref(e)))
+                evs.append(e)
+            self.split_event, self.keys_event, self.head_event, self.done_event = evs
+            self.stream = torch.cuda.Stream()
+
+    def __del__(self):
+        try:
+            for e in (self.split_event, self.keys_event, self.head_event, self.done_event):
+                if e is not None:
+                    L.load().czc_event_destroy(e)
+        except Exception:
+            pass
+
+    @staticmethod
+    def split_for(batch: int, seq: int) -> int:
+        """Sequences in the first range: half the batch when both halves keep 16-byte-aligned rows, else 0 (no split)."""
+        n = batch // 2
+        return n if (n > 0 and (n * seq) % 16 == 0) else 0
+
+    def _buf(self, name, rows, like):
+        b = self._bufs.get(name)
+        if b is None or b.shape != (rows, like.shape[1]) or b.device != like.device or b.dtype != like.dtype:
+            b = torch.empty(rows, like.shape[1], dtype=like.dtype, device=like.device)
+            self._bufs[name] = b
+        return b
+
+    @torch.no_grad()
+    def _gather_ranges(self, k, n):
+        """gathered [W * B, C], rank-major, from the ranges [0, n) and [n, B) of every rank's k"""
+        W, B = self.world, k.shape[0]
+        out = self._buf("out", W * B, k)
+        if n == 0:
+            return _all_gather_rows(out, k, self.group)
+        view = out.view(W, B, k.shape[1])
+        for name, lo, hi in (("lo", 0, n), ("hi", n, B)):
+            if name == "hi" and k.is_cuda:
+                L.check(L.load().czc_stream_wait_event(self.stream.cuda_stream, self.keys_event))
+            part = _all_gather_rows(self._buf(name, W * (hi - lo), k), k[lo:hi], self.group)
+            view[:, lo:hi].copy_(part.view(W, hi - lo, k.shape[1]))
+        return out
+
+    @torch.no_grad()
+    def gather(self, k: torch.Tensor, n: int = 0):
+        """Start the exchange of this rank's keys k [B, C]; call right after the key forward has been enqueued."""
+        if not k.is_cuda:
+            self.gathered = self._gather_ranges(k, n)
+            return
+        self._events()
+        lib = L.load()
+        L.check(lib.czc_event_record(self.keys_event, L.stream_ptr()))        # all of k is complete behind this point
+        first = self.split_event if n else self.keys_event
+        L.check(lib.czc_stream_wait_event(self.stream.cuda_stream, first))
+        with torch.cuda.stream(self.stream):
+            self.gathered = self._gather_ranges(k, n)
+
+    @torch.no_grad()
+    def enqueue(self, fn):
+        """fn(gathered) is enqueued on the side stream behind everything the main stream has issued so far (this step's
+        logits: they read the queue columns fn overwrites), and the main stream then waits for it: whatever reads the
+        queue or its pointer next -- the next step's logits, a checkpoint, int(queue_ptr) -- sees the enqueued keys."""
+        if self.stream is None:
+            return fn(self.gathered)
+        lib = L.load()
+        L.check(lib.czc_event_record(self.head_event, L.stream_ptr()))
+        L.check(lib.czc_stream_wait_event(self.stream.cuda_stream, self.head_event))
+        with torch.cuda.stream(self.stream):
+            fn(self.gathered)
+            L.check(lib.czc_event_record(self.done_event, self.stream.cuda_stream))
+        L.check(lib.czc_stream_wait_event(L.stream_ptr(), self.done_event))
+
+
 class DataParallel(nn.Module):
     """`.module` is the wrapped MoCo (same attribute the reference reads from its DDP wrapper)."""
 
@@ -55,15 +175,12 @@ class DataParallel(nn.Module):
                           and any(p.requires_grad for p in m._plist)]
         self._comm = None
         self._done = None
+        self._per_tile = False
         for enc in self._encoders:
             enc._range_hooks = [self._reduce_range]
+            enc._pre_grad_access = [self.wait]
+            enc._post_backward = [self._backward_enqueued]
             enc.backward_chunk_layers = chunk_layers if self._world > 1 else 0
-        if self._world > 1 and torch.cuda.is_available():
-            # The GEMMs' persistent launch sizes its grid to ALL the CUs; with RCCL's kernels holding some of them
-            # during the overlapped gradient all-reduce the last workgroups would start a whole pass late.  One
-            # workgroup per output tile degrades gracefully instead (include/czc.h, czc_gemm_set_tile).
-            from . import lib as L
-            L.check(L.load().czc_gemm_set_tile(16))
         if optimizer is not None:
             self.attach(optimizer)
 
@@ -86,12 +203,25 @@ class DataParallel(nn.Module):
             with torch.cuda.stream(self._comm):
                 self._comm.wait_event(ready)
                 average_(g, self._group)
-                self._done = torch.cuda.Event()
+                self._done = torch.cuda.Event()   # the stream is in order: the newest event covers every earlier range
                 self._done.record()
+            if not self._per_tile:
+                # The GEMMs' persistent launch sizes its grid to ALL the CUs; with RCCL's kernels holding some of them
+                # the last workgroups would start a whole pass late.  One workgroup per output tile degrades gracefully
+                # instead (include/czc.h, czc_gemm_set_tile) -- only for the launches that can run beside a collective:
+                # from the first range's all-reduce to the end of this backward.
+                L.check(L.load().czc_gemm_set_tile(16))
+                self._per_tile = True
         else:
             average_(g, self._group)
 
+    def _backward_enqueued(self, enc):
+        if self._per_tile:
+            L.check(L.load().czc_gemm_set_tile(0))
+            self._per_tile = False
+
     def wait(self):
+        """The main stream waits for every gradient all-reduce issued so far."""
         if self._done is not None:
             torch.cuda.current_stream().wait_event(self._done)
             self._done = None

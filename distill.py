@@ -96,7 +96,7 @@ def make_teacher(spec, student_tokenizer, vocab_size, pad_id, device):
 def teacher_dim(spec):
     if spec.startswith("synthetic"):
         return int(spec.split(":")[1]) if ":" in spec else 3584
-    ck = torch.load(os.path.join(spec, "checkpoint.pth"), map_location="cpu", weights_only=False)
+    ck = utils.read_checkpoint(os.path.join(spec, "checkpoint.pth"))
     from src.moco import resolve_model_config
     return resolve_model_config(ck["opt"].retriever_model_id)[0].hidden_size
 

@@ -30,12 +30,22 @@ extern "C" {
 #define CZC_ERR_INVALID 1
 #define CZC_ERR_HIP 2
 
-#define CZC_ABI_VERSION 2
+#define CZC_ABI_VERSION 3
 
 typedef void* czc_stream_t; /* hipStream_t */
+typedef void* czc_event_t;  /* hipEvent_t (timing disabled) */
 
 const char* czc_last_error(void);
 int czc_abi_version(void);
+
+/* Stream ordering without torch types: events the caller creates once and reuses (hipEventDisableTiming).
+ * czc_event_record(ev, s): ev marks the work enqueued on s so far; czc_stream_wait_event(s, ev): work enqueued on s
+ * afterwards starts only once ev has fired.  Neither blocks the host.  Used for the key all-gather / enqueue on a side
+ * stream (the queue columns an enqueue overwrites must have been read by this step's logits: write-after-read). */
+int czc_event_create(czc_event_t* ev);
+int czc_event_destroy(czc_event_t ev);
+int czc_event_record(czc_event_t ev, czc_stream_t stream);
+int czc_stream_wait_event(czc_stream_t stream, czc_event_t ev);
 
 /* ---------------------------------------------------------------------------------------------
  * Encoder shape (HF BertConfig as read by src/moco.py:226-229 / src/contriever.py:11-13)
@@ -94,12 +104,18 @@ int64_t czc_encoder_backward_scratch_bytes(const czc_bert_shape* s, int batch, i
  *   for attention, and pooling weights)
  *   training != 0 applies dropout with the counter RNG keyed by `seed` (pass the same seed to
  *   czc_encoder_backward).  workspace: czc_encoder_workspace_bytes(..) bytes, 256-B aligned.
- *   emb_out f32 [batch, hidden]. */
+ *   emb_out f32 [batch, hidden].
+ *   split_batch > 0 (only with save_for_backward == 0, i.e. the key encoder): the LAST layer and the pooling run
+ *   in two batch ranges, [0, split_batch) first; `split_event` (may be NULL) is recorded on `stream` as soon as
+ *   emb_out[0 .. split_batch) is complete, while the rest of the batch is still being encoded -- the caller's side
+ *   stream waits on it and starts the cross-GPU all-gather of those keys under this call's tail
+ *   (src/moco.py:272-287 via src/dist_utils.py:29-37 in the reference).  Embeddings do not depend on the split
+ *   (dropout draws of the second range use their own sites). */
 int czc_encoder_forward(const czc_bert_shape* s, const float* params_f32, const uint16_t* params_bf16,
                         const int64_t* ids, const uint8_t* mask, int batch, int seq,
                         int pooling, int normalize, int training, uint32_t seed,
                         int save_for_backward, void* workspace, int64_t workspace_bytes,
-                        float* emb_out, czc_stream_t stream);
+                        float* emb_out, int split_batch, czc_event_t split_event, czc_stream_t stream);
 
 /* grads_f32 (flat, same layout as params) += d(sum(emb * d_emb))/d(params)  when accumulate != 0,
  * or is overwritten when accumulate == 0.  `workspace` is the one the matching forward filled.
@@ -209,6 +225,13 @@ int czc_gemm_set_tile(int cfg);
  * czc_probe_read synchronises on the recorded events and returns their summed duration. */
 int czc_probe_arm(int a_layout, int b_layout, int epilogue, int M, int N, int K, int max_samples);
 int czc_probe_read(float* total_ms, int* count);
+/* Per-operation timing (bench / profiling only, off by default): while enabled every data-path operation of this
+ * library records a hipEvent pair on its launch stream under a name ("gemm a0 b0 epi2 65536x3072x768", "attention_bwd",
+ * "residual_ln_fwd", "adamw", ...).  czc_prof_enable(on) clears what was collected.  czc_prof_read waits for the events
+ * and writes one line per name:  name \t calls \t total_ms \t algorithmic FLOPs per call \t algorithmic bytes per call;
+ * it returns the size the whole report needs (call with len = 0 to size the buffer). */
+int czc_prof_enable(int on);
+int64_t czc_prof_read(char* buf, int64_t len);
 
 /* dst (+)= sum_z slabs[z]  (n elements each) */
 int czc_reduce_slabs(const float* slabs, int nslabs, int64_t n, float* dst, int accumulate,

@@ -76,7 +76,8 @@ def load_retriever(model_path, pooling="average", random_init=False):
     path = os.path.join(model_path, "checkpoint.pth")
     if not os.path.exists(path):
         raise FileNotFoundError(f"{path}: only local czc/contriever checkpoints can be loaded offline")
-    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    from src.utils import read_checkpoint
+    ckpt = read_checkpoint(path)
     opt = ckpt["opt"]
     state = ckpt["model"]
     if any("encoder_q." in key for key in state):

@@ -83,6 +83,8 @@ class _L2FromInit(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         enc = ctx.enc
+        for hook in enc._pre_grad_access:   # a gradient all-reduce may still be averaging the array (DataParallel)
+            hook()
         fresh = any(p.grad is None for p in enc._plist if p.requires_grad)
         grads = enc.flat_grads()
         if fresh:
@@ -107,6 +109,7 @@ class MoCo(nn.Module):
         self.moco_train_mode_encoder_k = opt.moco_train_mode_encoder_k
         self.weight_decay = opt.weight_decay
         self.weight_decay_from_init = opt.weight_decay_from_init
+        self.key_gather_split = True   # data parallel: last key-encoder layer in two halves, first half's all-gather under it
 
         retriever, tokenizer = self._load_retriever(opt.retriever_model_id, pooling=opt.pooling,
                                                     random_init=opt.random_init)
@@ -127,7 +130,7 @@ class MoCo(nn.Module):
         self._queue_version = -1
         self._head_ws = None
         self._stats = None
-        self._gather_buf = None
+        self._key_exchange = {}
         self._l2_anchor = None
 
     def _load_retriever(self, model_id, pooling, random_init):
@@ -184,18 +187,32 @@ class MoCo(nn.Module):
         ek.mark_mirror_fresh()
 
     @torch.no_grad()
-    def _dequeue_and_enqueue(self, keys, process_group=None):
-        """all-gather keys (rank order, over `process_group`) and overwrite queue[:, ptr:ptr+n] (reference :272-287)."""
-        w = dist_utils.get_world_size(process_group)
-        if w > 1:
-            if self._gather_buf is None or self._gather_buf.shape[0] != w * keys.shape[0]:
-                self._gather_buf = torch.empty(w * keys.shape[0], keys.shape[1], dtype=keys.dtype, device=keys.device)
-            keys = dist_utils.gather_nograd(keys.contiguous(), process_group, out=self._gather_buf)
+    def _enqueue_rows(self, keys):
+        """overwrite queue[:, ptr:ptr+n] with keys [n, C] (all ranks, rank order) and advance the pointer, on the device"""
         batch_size = keys.shape[0]
         assert self.queue_size % batch_size == 0, f"{batch_size}, {self.queue_size}"  # for simplicity
         qb = self._queue_mirror()
         L.check(L.load().czc_enqueue(keys.contiguous().data_ptr(), batch_size, keys.shape[1], self.queue_size,
                                      qb.data_ptr(), self.queue.data_ptr(), self.queue_ptr.data_ptr(), L.stream_ptr()))
+
+    @torch.no_grad()
+    def _dequeue_and_enqueue(self, keys, process_group=None):
+        """all-gather keys (rank order, over `process_group`) and overwrite queue[:, ptr:ptr+n] (reference :272-287).
+        Stand-alone form: `_step` splits it into the exchange started right behind the key encoder and the enqueue
+        behind the logits (`_exchange`)."""
+        if dist_utils.get_world_size(process_group) > 1:
+            kx = self._exchange(process_group)
+            kx.gather(keys.contiguous(), 0)
+            kx.enqueue(self._enqueue_rows)
+        else:
+            self._enqueue_rows(keys)
+
+    def _exchange(self, process_group):
+        from czech_contriever_amd.parallel import KeyExchange
+        kx = self._key_exchange.get(process_group)
+        if kx is None:
+            kx = self._key_exchange[process_group] = KeyExchange(process_group)
+        return kx
 
     def _compute_logits(self, q, k):
         """Materialised logits [B, 1+K] (debug / evaluation only; the training path never builds them)."""
@@ -211,11 +228,21 @@ class MoCo(nn.Module):
         bsz = q_tokens.size(0)
         q = self.encoder_q(input_ids=q_tokens, attention_mask=q_mask, normalize=self.norm_query)
 
+        w = dist_utils.get_world_size(process_group)
+        kx = self._exchange(process_group) if w > 1 else None
         with torch.no_grad():
             self._momentum_update_key_encoder()
             if not self.encoder_k.training and not self.moco_train_mode_encoder_k:
                 self.encoder_k.eval()
-            k = self.encoder_k(input_ids=k_tokens, attention_mask=k_mask, normalize=self.norm_doc)
+            if kx is not None:
+                # cross-GPU negatives: the first half of the keys is on its way to the other ranks while the key encoder
+                # finishes the second half; the second half travels under the InfoNCE head below (KeyExchange)
+                n_first = kx.split_for(bsz, k_tokens.size(1)) if self.key_gather_split else 0
+                kx._events()
+                k = self.encoder_k.encode(k_tokens, k_mask, normalize=self.norm_doc, split=(n_first, kx.split_event))
+                kx.gather(k, n_first)
+            else:
+                k = self.encoder_k(input_ids=k_tokens, attention_mask=k_mask, normalize=self.norm_doc)
 
         qb = self._queue_mirror()
         if self._head_ws is None or self._head_ws_key != (bsz, q.shape[1], self.queue_size, q.device):
@@ -235,7 +262,12 @@ class MoCo(nn.Module):
                 self._l2_anchor = torch.zeros(1, device=q.device, requires_grad=True)
             loss = loss + _L2FromInit.apply(self._l2_anchor, self.encoder_q, self._init_flat, float(self.weight_decay))
 
-        self._dequeue_and_enqueue(k, process_group)
+        # the enqueue overwrites queue columns this step's logits have just read (they must not contain this step's keys,
+        # reference :323 -> :338): it is ordered behind the head, and the next reader of the queue behind it
+        if kx is not None:
+            kx.enqueue(self._enqueue_rows)
+        else:
+            self._enqueue_rows(k)
 
         if len(stats_prefix) > 0:
             stats_prefix = stats_prefix + "/"

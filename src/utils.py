@@ -7,8 +7,9 @@ Kept: `set_optim(opt, model) -> (optimizer, scheduler)`, `WarmupLinearScheduler`
 `latest` symlink, `load(model_class, dir_path, opt, reset_params)`, `WeightedAvgStats`, `mean_pooling`,
 `init_logger`, `init_tb_logger`, `get_parameters`.
 Changed (each is a defect of the reference as committed): CosineScheduler imports
-math; torch.load passes weights_only=False (the file pickles the argparse Namespace);
-init_tb_logger's second argument is optional.  The optimiser is FusedAdamW: same hyper-parameters and
+math; checkpoints are read with torch.load(weights_only=True) plus an allow-list of the one non-tensor class the file
+holds (the options Namespace under "opt") -- the reference's bare torch.load fails on torch >= 2.6 and a full unpickle
+would run whatever a downloaded checkpoint contains; init_tb_logger's second argument is optional.  The optimiser is FusedAdamW: same hyper-parameters and
 state_dict layout as torch.optim.AdamW, one HIP launch over the flat parameter array."""
 from __future__ import annotations
 
@@ -57,6 +58,19 @@ def _unwrap(model):
     return model.module if hasattr(model, "module") else model
 
 
+def read_checkpoint(path, unsafe=False):
+    """torch.load of a `checkpoint.pth` (reference src/utils.py:78, src/contriever.py:108) that executes nothing from the
+    file: tensors, containers and numbers, plus the options object under "opt" (argparse.Namespace as src/options.py
+    parses it; types.SimpleNamespace as tests and bench build it).  Anything else in the pickle is refused; a caller who
+    trusts the file can opt in with unsafe=True (env CZC_UNSAFE_LOAD=1)."""
+    import argparse
+    import types
+    if unsafe or os.environ.get("CZC_UNSAFE_LOAD") == "1":
+        return torch.load(path, map_location="cpu", weights_only=False)
+    with torch.serialization.safe_globals([argparse.Namespace, types.SimpleNamespace]):
+        return torch.load(path, map_location="cpu", weights_only=True)
+
+
 def save(model, optimizer, scheduler, step, opt, dir_path, name):
     root = os.path.join(dir_path, "checkpoint")
     target = os.path.join(root, name)
@@ -78,7 +92,7 @@ def load(model_class, dir_path, opt, reset_params=False):
     epoch_path = os.readlink(dir_path) if os.path.islink(dir_path) else dir_path
     checkpoint_path = os.path.join(epoch_path, "checkpoint.pth")
     logger.info(f"loading checkpoint {checkpoint_path}")
-    checkpoint = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+    checkpoint = read_checkpoint(checkpoint_path)
     opt_checkpoint = checkpoint["opt"]
     model = model_class(opt_checkpoint)
     model.load_state_dict(checkpoint["model"], strict=True)
@@ -126,7 +140,9 @@ def set_optim(opt, model):
     if opt.optim != "adamw":
         raise NotImplementedError("optimizer class not implemented")
     from czech_contriever_amd.optim import FusedAdamW
-    wd = 0.0 if opt.weight_decay_from_init else opt.weight_decay
+    # --weight_decay_from_init: the reference builds AdamW WITHOUT a weight_decay argument (src/utils.py:139-142), so
+    # torch's default decoupled decay of 0.01 applies on top of the L2-from-init penalty; kept as it is there
+    wd = 0.01 if opt.weight_decay_from_init else opt.weight_decay
     optimizer = FusedAdamW(model, lr=opt.lr, betas=(opt.beta1, opt.beta2), eps=opt.eps, weight_decay=wd)
     kinds = {"linear": WarmupLinearScheduler, "cosine": CosineScheduler}
     if opt.scheduler not in kinds:

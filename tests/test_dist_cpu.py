@@ -42,6 +42,25 @@ def _worker(rank, world, port, out):
         dist.all_gather_object(all_digest, (digest, ptr))
         assert all(d == all_digest[0] for d in all_digest), all_digest
 
+        # the key exchange MoCo uses under data parallelism (czech_contriever_amd.parallel.KeyExchange): gathered in two
+        # batch ranges (first half early, second half late) or in one piece, the rows come out in the SAME rank-major
+        # order, so queue and pointer stay bit-identical to the unsplit path (and to the reference's cat(all_gather))
+        kx_split, kx_whole = parallel.KeyExchange(), parallel.KeyExchange()
+        assert parallel.KeyExchange.split_for(8, 256) == 4 and parallel.KeyExchange.split_for(1, 256) == 0
+        assert parallel.KeyExchange.split_for(6, 5) == 0 and parallel.KeyExchange.split_for(6, 16) == 3
+        qa, qb_, pa, pb = queue.clone(), queue.clone(), ptr, ptr
+        for step in range(10):
+            keys = O.det_uniform((B, C), 300 + 10 * step + rank)
+            got = {}
+            for name, kx, n in (("split", kx_split, B // 2), ("whole", kx_whole, 0)):
+                kx.gather(keys, n)
+                kx.enqueue(lambda rows, name=name: got.__setitem__(name, rows.clone()))
+            ref = torch.cat([O.det_uniform((B, C), 300 + 10 * step + r) for r in range(world)])   # rank order
+            assert torch.equal(got["split"], ref) and torch.equal(got["whole"], ref)
+            qa, pa = O.enqueue(qa, pa, got["split"])
+            qb_, pb = O.enqueue(qb_, pb, got["whole"])
+        assert torch.equal(qa, qb_) and pa == pb == (ptr + 10 * world * B) % K
+
         # autograd all-gather: each rank gets the SUM over ranks of the gradient of its slice
         x = O.det_uniform((B, C), 7 + rank).requires_grad_(True)
         g = dist_utils.gather(x)

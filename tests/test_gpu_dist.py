@@ -38,36 +38,51 @@ def _batches(step):
     return qt, qm, kt, km
 
 
-def _run(mdir, rank, world, steps=3):
-    from src import moco, utils
+def _run(mdir, rank, world, steps=3, split=True, mode="moco", update_freq=1, clip=None):
+    """mode "moco" / "inbatch"; update_freq micro-steps are accumulated per optimizer step (train.py:263-266: the gradient
+    all-reduce runs on every micro-step); clip = max gradient norm (train.py:314-322)"""
+    from src import inbatch, moco, utils
     from czech_contriever_amd.parallel import DataParallel
     dev = torch.device("cuda:0")
     opt = _opt(mdir)
-    model = moco.MoCo(opt)
     P = O.make_params(O.BertShape(**TINY), 71)
-    model.encoder_q.load_state_dict(P); model.encoder_k.load_state_dict(P)
-    with torch.no_grad():
-        model.queue.copy_(torch.nn.functional.normalize(O.det_uniform((128, 64), 72), dim=0))
+    if mode == "moco":
+        model = moco.MoCo(opt)
+        model.key_gather_split = split
+        model.encoder_q.load_state_dict(P); model.encoder_k.load_state_dict(P)
+        with torch.no_grad():
+            model.queue.copy_(torch.nn.functional.normalize(O.det_uniform((128, 64), 72), dim=0))
+    else:
+        model = inbatch.InBatch(opt)
+        model.encoder.load_state_dict(P)
     model = model.to(dev).train()
     optimizer, scheduler = utils.set_optim(opt, model)
     wrapped = DataParallel(model, optimizer, chunk_layers=1) if world > 1 else model
+    micro = 0
     for step in range(steps):
-        qt, qm, kt, km = _batches(step)
-        if world > 1:   # each rank takes its half of the batch
-            sl = slice(rank * 4, (rank + 1) * 4)
-            qt, qm, kt, km = qt[sl], qm[sl], kt[sl], km[sl]
-        loss, _ = wrapped(qt.to(dev), qm.to(dev), kt.to(dev), km.to(dev), stats_prefix="train")
-        loss.backward()
+        for _ in range(update_freq):
+            qt, qm, kt, km = _batches(micro)
+            micro += 1
+            if world > 1:   # each rank takes its half of the batch
+                sl = slice(rank * 4, (rank + 1) * 4)
+                qt, qm, kt, km = qt[sl], qm[sl], kt[sl], km[sl]
+            loss, _ = wrapped(qt.to(dev), qm.to(dev), kt.to(dev), km.to(dev), stats_prefix="train")
+            loss.backward()
+        if clip is not None:
+            optimizer.clip_grad_norm_(clip)
         optimizer.step(); scheduler.step(); wrapped.zero_grad()
     torch.cuda.synchronize()
-    return (model.encoder_q.flat_params.cpu(), model.encoder_k.flat_params.cpu(), model.queue.cpu(), int(model.queue_ptr))
+    enc = model.get_encoder()
+    if mode == "moco":
+        return (enc.flat_params.cpu(), model.encoder_k.flat_params.cpu(), model.queue.cpu(), int(model.queue_ptr))
+    return (enc.flat_params.cpu(),)
 
 
-def _worker(rank, world, port, mdir, out):
+def _worker(rank, world, port, mdir, out, kw=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        res = _run(mdir, rank, world)
+        res = _run(mdir, rank, world, **(kw or {}))
         out.put((rank, "ok", [t if isinstance(t, int) else t.numpy() for t in res]))
     except Exception as e:  # pragma: no cover
         import traceback
@@ -76,23 +91,36 @@ def _worker(rank, world, port, mdir, out):
         dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_process_with_the_joint_batch(tmp_path):
-    if not torch.cuda.is_available():
-        pytest.skip("no GPU")
-    mdir = str(tmp_path)
-    with open(os.path.join(mdir, "config.json"), "w") as f:
-        json.dump(dict(TINY, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0), f)
+def _two_ranks(mdir, **kw):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, mdir, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mdir, q, kw)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in procs], key=lambda x: x[0])
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), [r[1] for r in res]
-    (q0, k0, queue0, ptr0), (q1, k1, queue1, ptr1) = res[0][2], res[1][2]
+    return res[0][2], res[1][2]
+
+
+def _mdir(tmp_path):
+    mdir = str(tmp_path)
+    with open(os.path.join(mdir, "config.json"), "w") as f:
+        json.dump(dict(TINY, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0), f)
+    return mdir
+
+
+def test_two_ranks_equal_one_process_with_the_joint_batch(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    mdir = _mdir(tmp_path)
+    (q0, k0, queue0, ptr0), (q1, k1, queue1, ptr1) = _two_ranks(mdir)
+    # the key exchange in two batch ranges (last key-encoder layer split, first half gathered under it, side stream +
+    # events) leaves EVERYTHING bit-identical to the exchange in one piece: same rows in the same queue slots
+    (qw, kw_, queuew, ptrw), _ = _two_ranks(mdir, split=False)
+    assert (queue0 == queuew).all() and ptr0 == ptrw and (q0 == qw).all() and (k0 == kw_).all()
     # replicas stay bit-identical: same averaged gradients, same gathered keys in the same order
     assert (q0 == q1).all() and (k0 == k1).all() and (queue0 == queue1).all() and ptr0 == ptr1 == 24
     ref_q, ref_k, ref_queue, ref_ptr = _run(mdir, 0, 1)
@@ -102,3 +130,23 @@ def test_two_ranks_equal_one_process_with_the_joint_batch(tmp_path):
     # AdamW's first steps move weights by ~lr = 1e-3 per step whatever the gradient scale: compare directions
     assert float(dq.abs().max()) < 2.5e-3, float(dq.abs().max())
     assert float(dq.abs().mean()) < 2e-4, float(dq.abs().mean())
+
+
+@pytest.mark.parametrize("mode", ["moco", "inbatch"])
+def test_accumulation_and_clipping_under_data_parallel(tmp_path, mode):
+    """update_freq = 2 (the second backward accumulates into gradients whose all-reduce from the first may still be
+    pending), gradient-norm clipping before the step (it must see averaged gradients), and the in-batch objective (two
+    encoder backwards per micro-step): two ranks must match one process that sees the joint batch."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    mdir = _mdir(tmp_path)
+    kw = dict(mode=mode, update_freq=2, clip=0.05, steps=2)
+    r0, r1 = _two_ranks(mdir, **kw)
+    for a, b in zip(r0, r1):
+        assert (a == b).all() if not isinstance(a, int) else a == b          # replicas bit-identical
+    ref = _run(mdir, 0, 1, **kw)
+    dq = torch.from_numpy(r0[0]) - ref[0]
+    assert float(dq.abs().max()) < 2.5e-3 and float(dq.abs().mean()) < 2e-4, (float(dq.abs().max()), float(dq.abs().mean()))
+    if mode == "moco":
+        assert r0[3] == ref[3] == (2 * 2 * 8) % 64
+        assert float(abs(torch.from_numpy(r0[2]) - ref[2]).max()) < 2e-2

@@ -480,3 +480,30 @@ def test_attention_fused_backward_is_bitwise_reproducible(ops):
     a = ops.attention_backward(qkv, mask, ctx, dctx, lse, B, S, nh, p, seed, site)
     b = ops.attention_backward(qkv, mask, ctx, dctx, lse, B, S, nh, p, seed, site)
     assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
+
+
+def test_infonce_saturated_positive_is_exactly_zero(ops):
+    """README flags (un-normalised embeddings, T = 0.05): while the encoder is near its initialisation every positive
+    logit towers over the negatives, softmax is exactly one-hot in fp32 and the reference's loss AND gradient are exactly
+    0 (torch cross_entropy: z0 - lse(z) with lse == z0).  The head must reproduce the exact zeros: AdamW turns any
+    non-zero gradient, however small, into a full lr-sized step (found at config-1 size: a fused multiply-subtract left
+    the rounding residual of lpos * (1 / T) as the "gradient")."""
+    from oracle import moco_bert_oracle as O
+    B, C, K, T = 4, 768, 512, 0.05
+    base = O.det_uniform((1, C), 5) * 0.8 + 0.3
+    q = (base + 0.1 * O.det_uniform((B, C), 6)).to(dev())        # |q| ~ 22, q.k ~ 480: z0 ~ 9600 against negatives ~ +-50
+    k = (base + 0.1 * O.det_uniform((B, C), 7)).to(dev())
+    queue = O.init_queue(C, K, 0).to(dev())
+    qb = torch.empty(K, C, dtype=BF16, device=dev())
+    ops.queue_import(queue, qb)
+    ws = ops.infonce_workspace(B, C, K, dev())
+    for ls in (0.0,):
+        lse, stats = ops.infonce_forward(q, k, qb, T, ls, ws)
+        dq = ops.infonce_backward(q, k, qb, T, ls, lse, 1.0, ws)
+        qq = q.cpu().clone().requires_grad_(True)
+        loss, _ = O.infonce_loss(qq, k.cpu(), queue.cpu(), T, ls)
+        loss.backward()
+        assert float(loss) == 0.0 and float(qq.grad.abs().max()) == 0.0          # what the reference computes
+        assert float(stats[0]) == 0.0, float(stats[0])
+        assert float(dq.abs().max()) == 0.0, float(dq.abs().max())
+        assert float(stats[1]) == 100.0

@@ -368,3 +368,64 @@ def test_bert_base_full_depth_backward_vs_oracle(gpu):
                 for n, p in enc.named_parameters() if n.endswith("dense.weight") or n.endswith("query.weight")
                 or n.endswith("key.weight") or n.endswith("value.weight"))
     assert worst[0] >= 0.99, worst
+
+
+def test_weights_written_on_the_gpu_reach_the_bf16_mirror(gpu):
+    """forward, then load_state_dict / an in-place parameter write on the GPU-resident encoder, then forward: the matrix
+    products must use the NEW weights (the bf16 mirror is rebuilt), i.e. equal a fresh encoder built from them."""
+    enc, P, cfg_o = make_encoder(TINY, 5, "average", gpu)
+    enc.eval()
+    ids, mask = ragged_batch(4, 16, 1, 512, [16, 9, 3, 16])
+    ids, mask = ids.to(gpu), mask.to(gpu)
+    with torch.no_grad():
+        e0 = enc(input_ids=ids, attention_mask=mask).clone()
+        P2 = O.make_params(cfg_o, 6)
+        enc.load_state_dict(P2)                                    # on the GPU, after a forward has built the mirror
+        e1 = enc(input_ids=ids, attention_mask=mask).clone()
+        fresh, _, _ = make_encoder(TINY, 6, "average", gpu)
+        fresh.eval()
+        want = fresh(input_ids=ids, attention_mask=mask)
+        assert torch.equal(e1, want) and not torch.equal(e0, e1)
+        w = enc.get_parameter("encoder.layer.0.intermediate.dense.weight")
+        w.mul_(1.5)                                                # a torch-side in-place write through a parameter view
+        e2 = enc(input_ids=ids, attention_mask=mask)
+        fw = fresh.get_parameter("encoder.layer.0.intermediate.dense.weight")
+        fw.mul_(1.5)
+        assert torch.equal(e2, fresh(input_ids=ids, attention_mask=mask)) and not torch.equal(e2, e1)
+
+
+@pytest.mark.parametrize("shape_kw,B,S,lengths", [(TINY, 8, 24, [24, 17, 3, 24, 9, 24, 12, 20]),
+                                                   (BASE1, 6, 256, [256, 130, 27, 256, 77, 200])])
+def test_key_encoder_split_last_layer_is_bitwise_neutral(gpu, shape_kw, B, S, lengths):
+    """czc_encoder_forward(split_batch): the last layer + pooling in two batch ranges (so that the first half of the keys
+    can be all-gathered while the second half is still being encoded) must give bit-identical embeddings, and the event
+    recorded behind the first range must fire."""
+    import ctypes
+    from czech_contriever_amd import lib as L
+    enc, _, _ = make_encoder(shape_kw, 7, "average", gpu)
+    enc.eval()
+    ids, mask = ragged_batch(B, S, 8, shape_kw["vocab_size"], lengths)
+    ids, mask = ids.to(gpu), mask.to(gpu)
+    ev = ctypes.c_void_p()
+    L.check(L.load().czc_event_create(ctypes.byref(ev)))
+    with torch.no_grad():
+        whole = enc.encode(ids, mask, normalize=True).clone()
+        for n in (B // 2, 1, B - 1):
+            if (n * S) % 16:
+                continue
+            side = torch.cuda.Stream()
+            part = enc.encode(ids, mask, normalize=True, split=(n, ev))
+            L.check(L.load().czc_stream_wait_event(side.cuda_stream, ev))     # a side stream may read rows [0, n) from here on
+            with torch.cuda.stream(side):
+                first = part[:n].clone()
+            side.synchronize()
+            torch.cuda.synchronize()
+            assert torch.equal(part, whole), (n, float((part - whole).abs().max()))
+            assert torch.equal(first, whole[:n])
+    L.check(L.load().czc_event_destroy(ev))
+    with pytest.raises(RuntimeError):                              # the split is for passes nothing differentiates through
+        enc.train()
+        enc._forward_impl(ids, mask, False, save=True, split=None)
+        L.check(L.load().czc_encoder_forward(ctypes.byref(enc._shape), enc._flat.data_ptr(), enc.mirror().data_ptr(), ids.data_ptr(),
+                                             mask.data_ptr(), B, S, 0, 0, 0, 0, 1, enc._workspace(B, S, True).data_ptr(),
+                                             enc._workspace(B, S, True).numel(), whole.data_ptr(), B // 2, None, L.stream_ptr()))

@@ -133,8 +133,10 @@ def test_weight_decay_from_init_matches_oracle(tmp_path):
     with torch.no_grad():
         model.queue.copy_(queue)
     model = model.to(dev).train()
-    optimizer, scheduler = utils.set_optim(opt, model)   # weight_decay_from_init -> AdamW without decay (reference :139-142)
-    assert optimizer.param_groups[0]["weight_decay"] == 0.0
+    # weight_decay_from_init -> AdamW built WITHOUT a weight_decay argument (reference src/utils.py:139-142): torch's
+    # default decoupled decay 0.01 stays on
+    optimizer, scheduler = utils.set_optim(opt, model)
+    assert optimizer.param_groups[0]["weight_decay"] == 0.01
     st = O.MoCoState(cfg_o, P, queue, momentum=0.99, temperature=0.05, norm_query=True, norm_doc=True, l2_from_init=wd)
     for step in range(3):
         qt, qm = ragged_batch(8, 24, 7300 + step, 512, [24, 17, 3, 24, 9, 24, 12, 20])
@@ -143,7 +145,7 @@ def test_weight_decay_from_init_matches_oracle(tmp_path):
         loss.backward()
         optimizer.step(); scheduler.step(); model.zero_grad()
         ref, _, _, _ = st.forward_backward(qt, qm, kt, km)
-        st.optimizer_step(1e-2, weight_decay=0.0)
+        st.optimizer_step(1e-2, weight_decay=0.01)
         assert abs(float(loss.detach()) - float(ref)) < 2e-2 * max(1.0, abs(float(ref))), (step, float(loss.detach()), float(ref))
     assert float(loss.detach()) > 1.0   # the penalty term is active (InfoNCE alone is < 1 here at step 2)
 

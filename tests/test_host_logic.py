@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(lib.LIB_PATH)
     for name in declared:
         getattr(raw, name)
-    assert L.czc_abi_version() == 2
+    assert L.czc_abi_version() == 3
 
 
 def test_argument_checks_fail_without_launching():
@@ -32,7 +32,7 @@ def test_argument_checks_fail_without_launching():
     rc = L.czc_gemm_bf16(1, 0, 0, 64, 64, 64, None, 64, None, 64, None, 64, None, None, None, 1, None)
     assert rc != 0 and b"czc_gemm" in L.czc_last_error()
     s = lib.BertShape(512, 128, 2, 4, 256, 64, 2, 1e-12, 0.1, 0.1)  # head_dim 32
-    assert L.czc_encoder_forward(ctypes.byref(s), None, None, None, None, 1, 8, 0, 0, 0, 0, 0, None, 0, None, None) != 0
+    assert L.czc_encoder_forward(ctypes.byref(s), None, None, None, None, 1, 8, 0, 0, 0, 0, 0, None, 0, None, 0, None, None) != 0
     assert b"head_dim 64" in L.czc_last_error()
 
 
@@ -78,3 +78,66 @@ def test_scheduler_and_data_contract():
     ids, mask = data.build_mask([torch.tensor([5, 6, 7]), torch.tensor([9])])
     assert ids.tolist() == [[5, 6, 7], [9, 0, 0]] and mask.tolist() == [[True, True, True], [True, False, False]]
     assert ids.dtype == torch.int64 and mask.dtype == torch.bool
+
+
+def test_bench_starts_its_own_ranks_when_invoked_bare(monkeypatch):
+    """`python bench.py --gpus N` without a launcher (how the driver calls it) must start N ranks through
+    torch.distributed.run as a child process and pass the flags on; under a launcher (RANK set) it must not."""
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return types.SimpleNamespace(returncode=7)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7                                        # the launcher's exit code is ours
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_profiler_report_is_empty_without_launches():
+    from czech_contriever_amd import lib
+    L = lib.load()
+    assert L.czc_prof_enable(1) == 0
+    assert lib.prof_report() == []
+    assert L.czc_prof_enable(0) == 0
+
+
+def test_mirror_goes_stale_on_any_parameter_write():
+    """the bf16 weight mirror must be rebuilt after load_state_dict / in-place parameter writes, also once the
+    parameters have been re-pointed (p.data = view) and no longer share the flat array's version counter"""
+    from src.contriever import Contriever, bert_config
+    enc = Contriever(bert_config(vocab_size=64, hidden_size=64, num_hidden_layers=1, num_attention_heads=1,
+                                 intermediate_size=64, max_position_embeddings=16))
+    enc._flat = enc._flat.clone()      # what .cuda() does: new storage, parameters re-pointed at it
+    enc._rebind()
+    enc._mirror_version = enc._write_stamp()
+    w = enc.get_parameter("encoder.layer.0.output.dense.weight")
+    with torch.no_grad():
+        w.mul_(2.0)
+    assert enc._mirror_version != enc._write_stamp()
+    enc._mirror_version = enc._write_stamp()
+    enc.load_state_dict(enc.state_dict())
+    assert enc._mirror_version == -1
+    enc._mirror_version = enc._write_stamp()
+    enc.reset_parameters()
+    assert enc._mirror_version == -1
+    import copy
+    k = copy.deepcopy(enc)
+    assert torch.equal(k.flat_params, enc.flat_params) and k._salt != enc._salt
+    g = torch.Generator().manual_seed(0)
+    state = torch.get_rng_state()
+    copy.deepcopy(enc)
+    assert torch.equal(torch.get_rng_state(), state)       # the copy draws nothing from the torch RNG
