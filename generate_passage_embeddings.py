@@ -29,7 +29,7 @@ FLAGS = [
     ("--no_fp16", dict(action="store_true", help="store fp32 embeddings")),
     ("--no_title", dict(action="store_true", help="title not added to the passage body")),
     ("--lowercase", dict(action="store_true", help="lowercase text before encoding")),
-    ("--normalize_text", dict(action="store_true", help="refused on this path (src/normalize_text.py)")),
+    ("--normalize_text", dict(action="store_true", help="clean up dashes, quotes, controls before tokenising (src/normalize_text.py)")),
 ]
 
 

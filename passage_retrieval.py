@@ -42,7 +42,7 @@ FLAGS = [
     ("--lang", dict(nargs="+")),
     ("--dataset", dict(type=str, default="none")),
     ("--lowercase", dict(action="store_true", help="lowercase text before encoding")),
-    ("--normalize_text", dict(action="store_true", help="refused on this path (src/normalize_text.py)")),
+    ("--normalize_text", dict(action="store_true", help="clean up dashes, quotes, controls before tokenising (src/normalize_text.py)")),
 ]
 
 

@@ -233,10 +233,7 @@ class Collator(object):
 
 # ---- loading -------------------------------------------------------------------------------------------------------
 def _normalize(text):
-    try:
-        from src.normalize_text import normalize
-    except ImportError as e:   # the unicode normalisation tables are not part of the MI355X path
-        raise NotImplementedError("--normalize_text needs src/normalize_text.py (not built here)") from e
+    from src.normalize_text import normalize
     return normalize(text)
 
 

@@ -1,75 +1,75 @@
-"""Answer matching for retrieved passages (the DPR recipe the reference uses, src/evaluation.py:25-117).
+"""Answer matching for retrieved passages: the DPR recipe the reference's retrieval script scores with
+(reference src/evaluation.py:25-117, called from passage_retrieval.py:95-108).
 
-Host-side scoring of a finished retrieval: a passage "has the answer" when the lower-cased token sequence of any
-answer string occurs contiguously in the passage's token sequence, both NFD-normalised; tokens are runs of letters /
-digits / marks, or any other single character that is neither a separator nor a control.  `top_k_hits[i]` counts the
-questions answered within the first i+1 passages.  Only what passage_retrieval.py calls is built (the reader metrics
-and the retriever-inversion statistics of the reference file, :120-209, belong to other scripts)."""
+A passage "has the answer" when the token sequence of any answer string occurs contiguously in the passage's token
+sequence, both NFD-normalised and lower-cased; a token is a run of letters / digits / combining marks, or any single
+character that is neither a separator nor a control.  `calculate_matches` returns, for every rank r, how many questions
+were answered within their first r + 1 passages, plus the per-question hit lists.  Pinned against the reference's own
+functions on shared inputs (tests/golden/g14_text.json).  Only what passage_retrieval.py calls is built here (the reader
+metrics and retriever-inversion statistics of the reference file, :120-209, serve other scripts)."""
 import collections
 import logging
 import unicodedata
-from functools import partial
-from multiprocessing import Pool as ProcessPool
-from typing import List
+from multiprocessing import Pool
 
+import numpy as np
 import regex
 
 logger = logging.getLogger(__name__)
 
 QAMatchStats = collections.namedtuple("QAMatchStats", ["top_k_hits", "questions_doc_hits"])
 
+_TOKEN = regex.compile(r"[\p{L}\p{N}\p{M}]+|[^\p{Z}\p{C}]", flags=regex.IGNORECASE | regex.UNICODE | regex.MULTILINE)
+_SEP = "\x00"   # a control character: never part of a token
 
-class SimpleTokenizer(object):
-    ALPHA_NUM = r"[\p{L}\p{N}\p{M}]+"
-    NON_WS = r"[^\p{Z}\p{C}]"
 
-    def __init__(self):
-        self._regexp = regex.compile("(%s)|(%s)" % (self.ALPHA_NUM, self.NON_WS),
-                                     flags=regex.IGNORECASE + regex.UNICODE + regex.MULTILINE)
+class SimpleTokenizer:
+    """`tokenize(text, uncased=False) -> list[str]` (the one method of the reference's tokenizer that the scoring uses)."""
 
     def tokenize(self, text, uncased=False):
-        tokens = [m.group() for m in self._regexp.finditer(text)]
-        return [t.lower() for t in tokens] if uncased else tokens
+        found = _TOKEN.findall(text)
+        return [w.lower() for w in found] if uncased else found
 
 
-def _normalize(text):
-    return unicodedata.normalize("NFD", text)
+def _sequence(tokenizer, text):
+    """token sequence as one string, every token fenced by separators: sub-sequence search becomes substring search"""
+    return _SEP + _SEP.join(tokenizer.tokenize(unicodedata.normalize("NFD", text), uncased=True)) + _SEP
 
 
-def has_answer(answers, text, tokenizer) -> bool:
-    words = tokenizer.tokenize(_normalize(text), uncased=True)
+def has_answer(answers, text, tokenizer=None) -> bool:
+    tokenizer = tokenizer or SimpleTokenizer()
+    haystack = _sequence(tokenizer, text)
     for answer in answers:
-        want = tokenizer.tokenize(_normalize(answer), uncased=True)
-        n = len(want)
-        if any(words[i:i + n] == want for i in range(len(words) - n + 1)):
+        needle = _sequence(tokenizer, answer)
+        if needle == _SEP + _SEP:          # an answer without tokens matches anywhere (the empty slice equals itself)
+            return True
+        if needle in haystack:
             return True
     return False
 
 
-def check_answer(example, tokenizer) -> List[bool]:
+def _question_hits(example):
+    tokenizer = SimpleTokenizer()
     hits = []
-    for doc in example["ctxs"]:
-        if doc["text"] is None:
+    for passage in example["ctxs"]:
+        if passage["text"] is None:
             logger.warning("no doc in db")
             hits.append(False)
         else:
-            hits.append(has_answer(example["answers"], doc["text"], tokenizer))
+            hits.append(has_answer(example["answers"], passage["text"], tokenizer))
     return hits
 
 
-def calculate_matches(data: List, workers_num: int):
+def calculate_matches(data, workers_num):
     logger.info("Matching answers in top docs...")
-    fn = partial(check_answer, tokenizer=SimpleTokenizer())
     if workers_num and workers_num > 1 and len(data) > 1:
-        with ProcessPool(processes=min(workers_num, len(data))) as pool:
-            scores = pool.map(fn, data)
+        with Pool(processes=min(workers_num, len(data))) as pool:
+            per_question = pool.map(_question_hits, data)
     else:
-        scores = [fn(ex) for ex in data]
-    logger.info("Per question validation results len=%d", len(scores))
-    n_docs = len(data[0]["ctxs"])
-    top_k_hits = [0] * n_docs
-    for question_hits in scores:
-        best_hit = next((i for i, x in enumerate(question_hits) if x), None)
-        if best_hit is not None:
-            top_k_hits[best_hit:] = [v + 1 for v in top_k_hits[best_hit:]]
-    return QAMatchStats(top_k_hits, scores)
+        per_question = [_question_hits(example) for example in data]
+    logger.info("Per question validation results len=%d", len(per_question))
+    depth = len(data[0]["ctxs"])
+    first = np.zeros(depth + 1, dtype=np.int64)           # histogram of the rank of each question's first hit
+    for hits in per_question:
+        first[hits.index(True) if True in hits else depth] += 1
+    return QAMatchStats(np.cumsum(first[:depth]).tolist(), per_question)

@@ -74,8 +74,8 @@ def test_passage_files_and_text(tmp_path):
     assert retrieval.passage_text(got[0]) == "Vltava Vltava je řeka"
     assert retrieval.passage_text(got[0], no_title=True, lowercase=True) == "vltava je řeka"
     assert retrieval.passage_text({"text": "Bez Titulku"}) == "Bez Titulku"
-    with pytest.raises(NotImplementedError):
-        retrieval.passage_text(got[0], normalize=True)
+    odd = {"title": "T\u2014x", "text": "it\u2019s \u201cq\u201d 1\u22122 \u2026"}
+    assert retrieval.passage_text(odd, normalize=True) == "T-x it's \"q\" 1-2 ..."
 
 
 def test_answer_matching():
@@ -129,3 +129,25 @@ def test_command_lines_keep_the_reference_flags():
     b = ret.get_parser().parse_args(["--data", "x.jsonl"])
     assert (b.n_docs, b.validation_workers, b.per_gpu_batch_size, b.question_maxlength, b.indexing_batch_size,
             b.projection_size, b.n_subquantizers, b.n_bits, b.dataset) == (100, 32, 64, 512, 1000000, 768, 0, 8, "none")
+
+
+def test_text_helpers_match_reference_golden(golden_dir):
+    """src/normalize_text.normalize and src/evaluation.{SimpleTokenizer, has_answer, calculate_matches} against what the
+    reference's own functions returned for the same inputs (g14, oracle/make_golden_text.py): every code point below
+    U+3100, composed punctuation cases, 400 answer / passage pairs, one scored retrieval."""
+    import json
+    import os
+    from src.evaluation import SimpleTokenizer, calculate_matches, has_answer
+    from src.normalize_text import normalize
+    with open(os.path.join(golden_dir, "g14_text.json")) as f:
+        g = json.load(f)
+    for text, want in g["normalize"]:
+        assert normalize(text) == want, (text.encode("unicode_escape"), normalize(text), want)
+    tok = SimpleTokenizer()
+    for answers, text, want, tokens in g["has_answer"]:
+        assert tok.tokenize(text, uncased=True) == tokens, text
+        assert has_answer(answers, text, tok) == want, (answers, text)
+    stats = calculate_matches(g["matches"]["data"], 1)
+    assert list(stats.top_k_hits) == g["matches"]["top_k_hits"]
+    assert [list(r) for r in stats.questions_doc_hits] == g["matches"]["questions_doc_hits"]
+    assert calculate_matches(g["matches"]["data"], 2).top_k_hits == g["matches"]["top_k_hits"]
