@@ -175,8 +175,10 @@ __device__ __forceinline__ float gelu_f(float x) { return x * gelu_parts(x).cdf;
 // the same for 8 values, written stage by stage (all exponentials, all reciprocals, all polynomials ...): a
 // transcendental's result may not be used by the very next instructions, and element-at-a-time code made the compiler
 // pad every exp / rcp with s_nops (37 per 8 elements in the GELU epilogues)
-template <bool DERIV>
-__device__ __forceinline__ void gelu8(const float (&x)[8], float (&out)[8]) {
+// MODE 0: out = gelu(x);  1: out = gelu'(x);  2: out = gelu(x) and out2 = gelu'(x) from the same exponential,
+// reciprocal and polynomial (two more packed operations per pair than either alone)
+template <int MODE>
+__device__ __forceinline__ void gelu8(const float (&x)[8], float (&out)[8], float (&out2)[8]) {
   // written on float pairs (v_pk_mul / v_pk_fma: two elements per VALU slot) and with the polynomial made monic
   // (poly / a5 = (((t + b4) t + b3) t + b2) t + b1, a5 folded into the final 0.5): a packed fma takes ONE scalar
   // constant, so the a5 t + a4 of the plain Horner form cost a constant move per pair
@@ -208,9 +210,17 @@ __device__ __forceinline__ void gelu8(const float (&x)[8], float (&out)[8]) {
     const f2 h = p[i] * t[i] * e[i] * 0.5307027145f;       // 0.5 * erfc(|x| / sqrt 2)
     const f2 one_h = 1.0f - h;
     const f2 cdf = (f2){xv[i][0] >= 0.f ? one_h[0] : h[0], xv[i][1] >= 0.f ? one_h[1] : h[1]};
-    const f2 o = DERIV ? xv[i] * (e[i] * 0.39894228040143267794f) + cdf : xv[i] * cdf;
-    out[2 * i] = o[0];
-    out[2 * i + 1] = o[1];
+    if (MODE == 0 || MODE == 2) {
+      const f2 o = xv[i] * cdf;
+      out[2 * i] = o[0];
+      out[2 * i + 1] = o[1];
+    }
+    if (MODE == 1 || MODE == 2) {
+      const f2 o = xv[i] * (e[i] * 0.39894228040143267794f) + cdf;
+      float (&dst)[8] = (MODE == 1) ? out : out2;
+      dst[2 * i] = o[0];
+      dst[2 * i + 1] = o[1];
+    }
   }
 }
 __device__ __forceinline__ float dgelu_f(float x) {

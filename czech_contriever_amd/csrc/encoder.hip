@@ -8,7 +8,7 @@
 // Per layer, forward:   qkv = x Wqkv^T + b          (one fused [3H,H] GEMM, bias epilogue)
 //                        ctx = attention(qkv)        (flash-style, attention.hip)
 //                        y1  = ctx Wo^T + b ; x1 = LN(drop(y1) + x)
-//                        u,h = x1 W1^T + b, gelu(u)  (GELU fused in the GEMM epilogue)
+//                        g,h = gelu'(u), gelu(u), u = x1 W1^T + b  (GELU and its derivative fused in the GEMM epilogue)
 //                        y2  = h W2^T + b  ; x'  = LN(drop(y2) + x1)
 // Backward mirrors it; weight gradients are [N',K'] = dY^T X GEMMs whose operands are both read
 // through transposing LDS reads, split over the token dimension into fp32 slabs.

@@ -268,8 +268,9 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   // full K-tiles; edge tiles, a ragged last K-tile and huge matrices keep the bounds-checked per-lane pointers
   // (measured A/B: scalar base + lane offset: -6 % for the weight-gradient products, both operands MN-major, but
   //  +3..9 % with a K-major operand; those add the offset to the base on the VALU instead)
-  // (measured A/B: -2..-5 % everywhere except the dGELU epilogue kernel, which runs out of registers with it: +5 %)
-  constexpr bool USE_FAST = (EPI != EPI_DGELU);
+  // (measured A/B: -2..-5 %; the dGELU epilogue, which ran out of registers with it while it still evaluated gelu'
+  //  itself, is a plain multiply now)
+  constexpr bool USE_FAST = true;
   constexpr bool SADDR = (AL == 1 && BL == 1);   // else: the same offsets added to the base on the VALU (2 instructions per piece)
   const bool fast = USE_FAST && a.fast_addr && row0 + BM <= a.M && col0 + BN <= a.N;
   unsigned off_a[PER_A], off_b[PER_B];
@@ -786,25 +787,28 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
       const unsigned off = seg_off(it);
       const u32x4 v = sv[itp];
       if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU1) {
-        if (EPI == EPI_BIAS_GELU) __builtin_amdgcn_raw_buffer_store_b128(v, rc, off, 0, 0);
-        float xin[8], gl[8];
+        // two outputs: C = gelu'(u) -- all the backward needs of the pre-activation (dX = dH . gelu'(u); dW1 reads x1, dW2
+        // reads h), so its epilogue is a multiply instead of a second exp / rcp / polynomial per element -- and C2 = gelu(u)
+        float xin[8], gl[8], dg[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { xin[2 * e] = bflo(v[e]); xin[2 * e + 1] = bfhi(v[e]); }
-        gelu8<false>(xin, gl);
+        if (EPI == EPI_BIAS_GELU) gelu8<2>(xin, gl, dg);
+        else gelu8<0>(xin, gl, dg);
         u32x4 g;
+        if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[e] = pack2bf(dg[2 * e], dg[2 * e + 1]);
+          __builtin_amdgcn_raw_buffer_store_b128(g, rc, off, 0, 0);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) g[e] = pack2bf(gl[2 * e], gl[2 * e + 1]);
         __builtin_amdgcn_raw_buffer_store_b128(g, EPI == EPI_BIAS_GELU ? rc2 : rc, off, 0, 0);
       } else if (EPI == EPI_DGELU) {
-        const u32x4 u = au[it];
-        float xin[8], dg[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { xin[2 * e] = bflo(u[e]); xin[2 * e + 1] = bfhi(u[e]); }
-        gelu8<true>(xin, dg);
+        const u32x4 u = au[it];   // gelu'(pre-activation), as the forward stored it
         u32x4 g;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float lo = bflo(v[e]) * dg[2 * e], hi = bfhi(v[e]) * dg[2 * e + 1];
+          const float lo = bflo(v[e]) * bflo(u[e]), hi = bfhi(v[e]) * bfhi(u[e]);
           g[e] = pack2bf(lo, hi);
           if (m < a.M) { csum[2 * e] += lo; csum[2 * e + 1] += hi; }
         }

@@ -55,17 +55,19 @@ __global__ __launch_bounds__(256) void head_final_kernel(const float* __restrict
   se = wave_sum(se);
   sm = wave_sum(sm);
   if (lane != 0) return;
-  // the positive logit as ONE rounded fp32 value, as the reference's `logits / T` tensor holds it (__fmul_rn: never fused
-  // into the subtractions below).  With `lpos * invT` the compiler contracted `lse - z0` into fma(-lpos, invT, lse), i.e.
-  // subtracted the UNROUNDED product: when the positive dominates (lse == z0; every early step with the README flags)
-  // loss and coefficient came out as the product's rounding residual instead of exactly 0, and AdamW -- which
-  // normalises any non-zero gradient to a full-size step -- moved every weight by lr along that noise.
-  const float z0 = __fmul_rn(lpos[b], invT);
+  // the positive logit as ONE rounded fp32 value, as the reference's `logits / T` tensor holds it: never fused into the
+  // subtractions below.  With a bare `lpos * invT` the compiler contracted `z0 - M` (and `z0 - lse` in the backward) into
+  // fma(lpos, invT, -M), i.e. subtracted from the UNROUNDED product: when the positive dominates (lse == z0; every early
+  // step with the README flags) exp(z0 - M) came out as exp(rounding residual) instead of 1, loss and coefficient as
+  // +-1e-4 instead of exactly 0, and AdamW -- which normalises any non-zero gradient to a full-size step -- moved
+  // every weight by lr along that noise.
+  float z0 = lpos[b] * invT;
+  asm volatile("" : "+v"(z0));   // (__fmul_rn is a plain `*` in this toolchain's headers: the empty asm is what keeps the product rounded)
   const float M = fmaxf(mx, z0);
   const float tot = se * __expf(mx - M) + __expf(z0 - M);
   const float lse = M + __logf(tot);
   lse_out[b] = lse;
-  rowloss[b] = (1.0f - ls) * __fsub_rn(lse, z0) + ls * (lse - (sm + z0) / (float)(Kq + 1));
+  rowloss[b] = (1.0f - ls) * (lse - z0) + ls * (lse - (sm + z0) / (float)(Kq + 1));
   rowok[b] = (z0 >= mx) ? 1.0f : 0.f;   // argmax picks column 0 on ties, as torch.argmax does
 }
 
@@ -120,8 +122,9 @@ __global__ __launch_bounds__(256) void head_bwd_final_kernel(const float* __rest
   const int b = (int)((i * 4) / C);
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   for (int z = 0; z < nslabs; ++z) s += ((const f32x4*)slabs)[(int64_t)z * n4 + i];
-  const float z0 = __fmul_rn(lpos[b], invT);   // the same rounded value head_final_kernel folded into lse (see there)
-  const float coef0 = __expf(__fsub_rn(z0, lse[b])) - (1.0f - ls) - ls / (float)(Kq + 1);
+  float z0 = lpos[b] * invT;   // the same rounded value head_final_kernel folded into lse (see there)
+  asm volatile("" : "+v"(z0));
+  const float coef0 = __expf(z0 - lse[b]) - (1.0f - ls) - ls / (float)(Kq + 1);
   ((f32x4*)dq)[i] = (s + ((const f32x4*)k)[i] * coef0) * scale;
 }
 

@@ -203,8 +203,8 @@ int czc_cast_bf16(const float* src, uint16_t* dst, int64_t n, czc_stream_t strea
 
 #define CZC_EPI_STORE 0      /* C bf16 = acc */
 #define CZC_EPI_BIAS 1       /* C bf16 = acc + bias[n] */
-#define CZC_EPI_BIAS_GELU 2  /* C = u = acc + bias ; C2 = gelu(u) */
-#define CZC_EPI_DGELU 3      /* C = acc * gelu'(aux[m][n]) */
+#define CZC_EPI_BIAS_GELU 2  /* u = acc + bias ; C = gelu'(u) (what the backward needs of u) ; C2 = gelu(u) */
+#define CZC_EPI_DGELU 3      /* C = acc * aux[m][n]  (aux = the gelu'(u) CZC_EPI_BIAS_GELU stored) */
 #define CZC_EPI_ADD 4        /* C = acc + aux[m][n] */
 #define CZC_EPI_F32 5        /* C f32 [splitk][M][ldc] = partial acc (no reduction) */
 

@@ -278,12 +278,15 @@ def test_gemm_epilogues(ops):
     aux = rnd(M, N, seed=31, dtype=BF16)
     acc = a.float() @ b.float().t()
     report("bias", ops.gemm(A, Bm, epilogue="bias", bias=bias), acc + bias, 5e-2, 8e-3)
-    u, h = ops.gemm(A, Bm, epilogue="bias_gelu", bias=bias)
-    report("u", u, acc + bias, 5e-2, 8e-3)
-    report("gelu(u)", h, torch.nn.functional.gelu(u.float()), 1e-2, 8e-3)
-    x = aux.float().requires_grad_(True)
-    torch.nn.functional.gelu(x).sum().backward()
-    report("dgelu", ops.gemm(A, Bm, epilogue="dgelu", aux=aux), acc.to(BF16).float() * x.grad, 5e-2, 1e-2)
+    # FFN-up forward: C = gelu'(u), C2 = gelu(u), u = acc + bias rounded to bf16 (what the kernel evaluates both on)
+    dg, h = ops.gemm(A, Bm, epilogue="bias_gelu", bias=bias)
+    u = (acc + bias).to(BF16).float().requires_grad_(True)
+    ref_h = torch.nn.functional.gelu(u)
+    ref_h.sum().backward()
+    report("gelu(u)", h, ref_h.detach(), 1e-2, 8e-3)
+    report("gelu'(u)", dg, u.grad, 1e-2, 8e-3)
+    # its backward: C = acc * aux, aux = the stored derivative
+    report("dgelu", ops.gemm(A, Bm, epilogue="dgelu", aux=aux), acc.to(BF16).float() * aux.float(), 5e-2, 1e-2)
     report("add", ops.gemm(A, Bm, epilogue="add", aux=aux), acc.to(BF16).float() + aux.float(), 5e-2, 8e-3)
 
 
