@@ -278,30 +278,41 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_res_kernel(const AttnArgs a) 
   const float c2 = 0.125f * LOG2E;
   const bf16_t* base = a.qkv + (size_t)b * S * H3 + hh * 64;
 
-  // K and V rows -> LDS (rows past S are zero: their scores are masked out below)
+  // Every global load of the prologue is issued before the first wait (ONE memory round trip, one barrier): the K and V
+  // rows for the LDS images (rows past S are zero: their scores are masked out below), this wave's Q fragments and the
+  // key's mask byte.  (Q used to be fetched after the K / V images had been written and synchronised: a second round
+  // trip with every wave of the workgroup parked -- rocprofv3: 43 % of the wave cycles in s_waitcnt / s_barrier.)
+  uint4 kv[4], vv[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int id = tid + 512 * i, row = id >> 3, c = id & 7;
-    uint4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+    kv[i] = vv[i] = (uint4){0u, 0u, 0u, 0u};
     if (row < S) {
-      kv = *(const uint4*)(base + a.H + (size_t)row * H3 + c * 8);
-      vv = *(const uint4*)(base + 2 * a.H + (size_t)row * H3 + c * 8);
+      kv[i] = *(const uint4*)(base + a.H + (size_t)row * H3 + c * 8);
+      vv[i] = *(const uint4*)(base + 2 * a.H + (size_t)row * H3 + c * 8);
     }
-    *(uint4*)(kt + row * 128 + ((c ^ swz64(row)) << 4)) = kv;
-    *(uint4*)(vt + row * 128 + ((c ^ swz64(row)) << 4)) = vv;
-  }
-  if (tid < 8) padflag[tid] = 0;
-  __syncthreads();
-  if (tid < spad) {
-    const bool valid = tid < S && a.mask[(size_t)b * S + tid];
-    mb[tid] = valid ? 0.f : NEG_MASK;
-    if (!valid) padflag[tid >> 5] = 1;
   }
   bf16x8 bq[4];
   {
     int qr = q0 + r; if (qr > S - 1) qr = S - 1;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) bq[ks] = ld_frag_global(base + (size_t)qr * H3 + 16 * ks + 8 * h);
+  }
+  const bool kvalid = tid < S && a.mask[(size_t)b * S + (tid < S ? tid : 0)];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = tid + 512 * i, row = id >> 3, c = id & 7;
+    *(uint4*)(kt + row * 128 + ((c ^ swz64(row)) << 4)) = kv[i];
+    *(uint4*)(vt + row * 128 + ((c ^ swz64(row)) << 4)) = vv[i];
+  }
+  if (tid < 256) {   // thread t owns key t: waves 0-3; a 32-key tile is one half of a wave
+    mb[tid] = kvalid ? 0.f : NEG_MASK;
+    const unsigned long long bad = __ballot(!kvalid && tid < spad);
+    if (lane == 0) {
+      padflag[2 * wave] = (bad & 0xffffffffull) != 0;
+      padflag[2 * wave + 1] = (bad >> 32) != 0;
+    }
   }
   __syncthreads();
   if (!active) return;
@@ -382,18 +393,23 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_res_kernel(const AttnArgs a) 
   l = xor32_sum(l);
   const float inv = (DROP ? a.inv_keep : 1.0f) / l;
   const int q = q0 + r;
-  if (q < S) {
-    bf16_t* dst = a.out + ((size_t)b * S + q) * a.H + hh * 64;
+  // A row's 8-byte pieces sit in lanes r (columns 8g .. 8g+3) and r + 32 (8g+4 .. 8g+7): one half-exchange per dword
+  // (v_permlane32_swap) turns the pieces of two groups g, g+1 into 16 contiguous bytes per lane -- lanes < 32 get all of
+  // group g, lanes >= 32 all of group g + 1 -- so the row leaves in 4 dwordx4 stores per lane instead of 8 dwordx2 (the
+  // store tail is instruction-bound, not byte-bound)
+  {
+    bf16_t* dst = a.out + ((size_t)b * S + (q < S ? q : 0)) * a.H + hh * 64 + (h ? 8 : 0);
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        uint2 w;
-        w.x = pack2bf(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv);
-        w.y = pack2bf(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
-        *(uint2*)(dst + 32 * dt + 8 * g + 4 * h) = w;
+      for (int g = 0; g < 4; g += 2) {
+        uint32_t ax = pack2bf(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv), ay = pack2bf(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        uint32_t bx = pack2bf(o[dt][4 * g + 4] * inv, o[dt][4 * g + 5] * inv), by = pack2bf(o[dt][4 * g + 6] * inv, o[dt][4 * g + 7] * inv);
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ax), "+v"(bx));
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ay), "+v"(by));
+        if (q < S) *(uint4*)(dst + 32 * dt + 8 * g) = make_uint4(ax, ay, bx, by);
       }
-    if (h == 0) a.lse[((size_t)b * a.nh + hh) * S + q] = (m + __log2f(l)) * LN2;
+    if (q < S && h == 0) a.lse[((size_t)b * a.nh + hh) * S + q] = (m + __log2f(l)) * LN2;
   }
 }
 
