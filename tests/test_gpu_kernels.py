@@ -354,7 +354,11 @@ def _attn_ref(qkv, mask, B, S, nh, keep=None, p=0.0):
 
 @pytest.mark.parametrize("B,S,nh,lengths", [(2, 256, 12, [256, 130]), (5, 24, 2, [24, 17, 1, 9, 24]),
                                             (3, 100, 4, [100, 64, 33]), (2, 320, 2, [320, 200]),
-                                            (3, 27, 2, [27, 13, 1]), (2, 1, 1, [1, 1]), (1, 512, 1, [500])])
+                                            (3, 27, 2, [27, 13, 1]), (2, 1, 1, [1, 1]), (1, 512, 1, [500]),
+                                            # more (batch, head) items than CUs: the persistent forward (workgroups walk over
+                                            # items, the next item's K / V arrive by LDS DMA meanwhile); 288, 300 and 1030 items
+                                            (24, 256, 12, [256, 130, 27, 1] * 6), (30, 100, 10, [100, 64, 33] * 10),
+                                            (103, 27, 10, [27, 13, 1, 20] * 25 + [27, 5, 9])])
 def test_attention_fwd_bwd(ops, B, S, nh, lengths):
     H = nh * 64
     qkv = rnd(B * S, 3 * H, seed=1, scale=1.0, dtype=BF16)
@@ -378,10 +382,10 @@ def test_attention_fwd_bwd(ops, B, S, nh, lengths):
     report("attn dV", d[:, :, 2], g[:, :, 2], 3e-2, 2e-2)
 
 
-@pytest.mark.parametrize("S", [128, 252, 320])   # (multiples of 4: the draw index pitch is S rounded up to 4) <= 256: the single-pass backward; 320: the dQ / dK+dV kernel pair
-def test_attention_dropout_matches_masked_reference(ops, S):
+@pytest.mark.parametrize("S,B,nh", [(128, 2, 2), (252, 2, 2), (320, 2, 2), (128, 23, 12)])   # (multiples of 4: the draw index pitch is S rounded up to 4) <= 256: the single-pass backward; 320: the dQ / dK+dV kernel pair; 23 x 12 = 276 items: the persistent forward
+def test_attention_dropout_matches_masked_reference(ops, S, B, nh):
     from tests.dropout_ref import keep_mask
-    B, nh, p, seed, site = 2, 2, 0.1, 7, 16
+    p, seed, site = 0.1, 7, 16
     H = nh * 64
     qkv = rnd(B * S, 3 * H, seed=3, dtype=BF16)
     mask = torch.ones(B, S, dtype=torch.bool, device=dev())
