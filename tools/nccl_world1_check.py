@@ -27,3 +27,23 @@ dist.barrier()
 torch.cuda.synchronize()
 print("ok", float(x.sum()), tuple(k.shape), float(t))
 dist.destroy_process_group()
+# the key exchange MoCo runs under data parallelism, on the RCCL backend with one rank: side stream, czc events, two batch
+# ranges gathered separately and assembled rank-major, the enqueue ordered behind the main stream, main waits for it
+dist.init_process_group("nccl", device_id=dev)
+from czech_contriever_amd.parallel import KeyExchange
+import czech_contriever_amd.parallel as par
+kx = KeyExchange()
+kx.world = 1
+par_world = par.world
+keys = torch.randn(8, 16, device=dev)
+got = {}
+for n in (4, 0):
+    kx._events()
+    from czech_contriever_amd import lib as L
+    L.check(L.load().czc_event_record(kx.split_event, L.stream_ptr()))
+    kx.gather(keys, n)
+    kx.enqueue(lambda rows, n=n: got.__setitem__(n, rows.clone()))
+torch.cuda.synchronize()
+assert torch.equal(got[4], keys) and torch.equal(got[0], keys)
+print("key exchange on nccl (1 rank): ok")
+dist.destroy_process_group()
