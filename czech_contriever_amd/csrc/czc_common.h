@@ -175,52 +175,51 @@ __device__ __forceinline__ float gelu_f(float x) { return x * gelu_parts(x).cdf;
 // the same for 8 values, written stage by stage (all exponentials, all reciprocals, all polynomials ...): a
 // transcendental's result may not be used by the very next instructions, and element-at-a-time code made the compiler
 // pad every exp / rcp with s_nops (37 per 8 elements in the GELU epilogues)
-// MODE 0: out = gelu(x);  1: out = gelu'(x);  2: out = gelu(x) and out2 = gelu'(x) from the same exponential,
-// reciprocal and polynomial (two more packed operations per pair than either alone)
+// The GEMM epilogues' form, eight values at a time.  MODE 0: out = gelu(x);  1: out = gelu'(x);  2: out = gelu(x) and
+// out2 = gelu'(x).  Their results are rounded to bf16 (2^-9 relative), so Phi is an odd polynomial here instead of the
+// exp + rcp + quartic above:  Phi(x) - 0.5 = t P(t^2),  t = clamp(x, -4, 4),  P of degree 7 (weighted minimax fit,
+// |error of Phi| <= 5.3e-5 in fp32 arithmetic over all x -- beyond +-4 the true tail is 3.2e-5 --, gelu within 1.3e-4
+// relative for x > -1 and 4.2e-4 absolute anywhere): 12 VALU operations per value and no transcendental, against ~22
+// with two transcendentals (rocprofv3: the bias+GELU epilogue issued 2 000 vector instructions per wave and output tile,
+// 49 M per FFN-up launch, with the matrix pipe idle behind them).  The derivative adds x phi(x) with one v_exp_f32.
 template <int MODE>
 __device__ __forceinline__ void gelu8(const float (&x)[8], float (&out)[8], float (&out2)[8]) {
-  // written on float pairs (v_pk_mul / v_pk_fma: two elements per VALU slot) and with the polynomial made monic
-  // (poly / a5 = (((t + b4) t + b3) t + b2) t + b1, a5 folded into the final 0.5): a packed fma takes ONE scalar
-  // constant, so the a5 t + a4 of the plain Horner form cost a constant move per pair
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  f2 xv[4], e[4], t[4], p[4];
+  // Stage by stage over the eight values, the stages fenced for the scheduler: a dependent v_pk_fma_f32 right behind the
+  // one that feeds it costs a wait state (hipcc serialised each pair's Horner chain and put an s_nop between every two
+  // steps: 560 per output tile); with four independent pairs per stage the next dependent use is four instructions away.
+  float t[8], s[8], p[8], e[8];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) xv[i] = (f2){x[2 * i], x[2 * i + 1]};
+  for (int i = 0; i < 8; ++i) {
+    t[i] = __builtin_amdgcn_fmed3f(x[i], -4.0f, 4.0f);
+    s[i] = t[i] * t[i];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (MODE != 0) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const f2 q = xv[i] * xv[i] * -0.72134752044448170368f;
-    e[i] = (f2){__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+    for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(fmaf(s[i], -0.72134752044448170368f, -1.32574806473616f));  // phi(t)
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const f2 az = (f2){fabsf(xv[i][0]), fabsf(xv[i][1])};
-    const f2 d = az * (0.3275911f * 0.70710678118654752440f) + 1.0f;
-    t[i] = (f2){__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-  }
+  for (int i = 0; i < 8; ++i) p[i] = fmaf(-1.5807964419e-09f, s[i], 1.2171171661e-07f);
+  __builtin_amdgcn_sched_barrier(0);
+#define CZC_HORNER(C)                                                \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) p[i] = fmaf(p[i], s[i], C); \
+  __builtin_amdgcn_sched_barrier(0);
+  CZC_HORNER(-4.1008809444e-06f)
+  CZC_HORNER(8.0667571337e-05f)
+  CZC_HORNER(-1.0482055429e-03f)
+  CZC_HORNER(9.6648779952e-03f)
+  CZC_HORNER(-6.6175384782e-02f)
+  CZC_HORNER(3.9884751216e-01f)
+#undef CZC_HORNER
+  float v[8];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) p[i] = t[i] + -1.3690829039465937f;
+  for (int i = 0; i < 8; ++i) v[i] = t[i] * p[i];                      // Phi - 0.5
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) p[i] = p[i] * t[i] + 1.3391807712338357f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) p[i] = p[i] * t[i] + -0.2680377622225258f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) p[i] = p[i] * t[i] + 0.24008694984732362f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const f2 h = p[i] * t[i] * e[i] * 0.5307027145f;       // 0.5 * erfc(|x| / sqrt 2)
-    const f2 one_h = 1.0f - h;
-    const f2 cdf = (f2){xv[i][0] >= 0.f ? one_h[0] : h[0], xv[i][1] >= 0.f ? one_h[1] : h[1]};
-    if (MODE == 0 || MODE == 2) {
-      const f2 o = xv[i] * cdf;
-      out[2 * i] = o[0];
-      out[2 * i + 1] = o[1];
-    }
-    if (MODE == 1 || MODE == 2) {
-      const f2 o = xv[i] * (e[i] * 0.39894228040143267794f) + cdf;
-      float (&dst)[8] = (MODE == 1) ? out : out2;
-      dst[2 * i] = o[0];
-      dst[2 * i + 1] = o[1];
-    }
+  for (int i = 0; i < 8; ++i) {
+    if (MODE == 0 || MODE == 2) out[i] = fmaf(x[i], v[i], 0.5f * x[i]);
+    if (MODE == 1) out[i] = fmaf(t[i], e[i], v[i] + 0.5f);
+    if (MODE == 2) out2[i] = fmaf(t[i], e[i], v[i] + 0.5f);
   }
 }
 __device__ __forceinline__ float dgelu_f(float x) {
