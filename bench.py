@@ -123,7 +123,8 @@ def cpu_baseline(seq, cpu_batch=8, steps=2):
     med = sorted(times[1:])[len(times[1:]) // 2]
     return {"value": round(cpu_batch / med, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
             "sample": f"{steps} full fp32 micro-steps (1 warm-up) of the CPU oracle at B={cpu_batch}, S={seq}, "
-                      f"bert-base, queue 8192, dropout on; median {med:.2f} s/step"}
+                      f"bert-base, queue 8192, dropout on; median {med:.2f} s/step; {cores} threads = the CPU share this job "
+                      f"is allowed (cgroup quota; the host shows {os.cpu_count()} logical CPUs, which a one-GPU job may not occupy)"}
 
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3    # MI355X fp32 MFMA (MI355X_MICROARCH.md): 256 CUs x 256 FLOP/clk x 2.4 GHz
