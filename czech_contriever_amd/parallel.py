@@ -96,6 +96,9 @@ class KeyExchange:
             self.split_event, self.keys_event, self.head_event, self.done_event = evs
             self.stream = torch.cuda.Stream()
 
+    def __deepcopy__(self, memo):
+        return KeyExchange(self.group)   # events, stream and buffers belong to one object: a copy makes its own on first use
+
     def __del__(self):
         try:
             for e in (self.split_event, self.keys_event, self.head_event, self.done_event):
@@ -106,7 +109,8 @@ class KeyExchange:
 
     @staticmethod
     def split_for(batch: int, seq: int) -> int:
-        """Sequences in the first range: half the batch when both halves keep 16-byte-aligned rows, else 0 (no split)."""
+        """Sequences in the first range: half the batch (0 = no split: a single sequence, or token counts that would leave
+        the second range's rows off the 16-token grid the row kernels were measured on)."""
         n = batch // 2
         return n if (n > 0 and (n * seq) % 16 == 0) else 0
 
