@@ -247,3 +247,64 @@ def test_config1_sized_steps_match_oracle(tmp_path):
         assert abs(float(stats["train/stdk"][0]) - float(rs["stdk"])) < 1e-2 * max(1.0, float(rs["stdk"]))
         assert int(model.queue_ptr) == st.ptr == ((step + 1) * B) % 512
     assert float((model.queue.cpu() - st.queue).abs().max()) < 3e-2 * float(st.queue.abs().max())
+
+
+def test_headline_config_micro_steps_match_oracle(tmp_path):
+    """BASELINE.json configs[1] (the bench's workload) at its stated shapes -- bert-base-sized encoder (12 layers, H 768, I 3072,
+    vocabulary 30 522), chunk_length 256, queue_size 131 072, temperature 0.05, momentum 0.9995, README flags -- with the
+    per-GPU batch cut from 256 to 32 so that the fp32 CPU oracle finishes three full micro-steps in about a minute:
+    q fwd/bwd, EMA, k fwd, InfoNCE against the 131 072 slots, enqueue, AdamW.  Dropout off.  Step 0 is the saturated case
+    (loss and gradient exactly 0 in the reference); from step 1 on the keys enqueued before are hard negatives."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from src import moco, utils
+    dev = torch.device("cuda:0")
+    mdir = str(tmp_path / "bert-base-sized")
+    os.makedirs(mdir)
+    with open(os.path.join(mdir, "config.json"), "w") as f:
+        json.dump(dict(BERT_BASE_UNCASED, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0), f)
+    K = 131072
+    opt = types.SimpleNamespace(
+        queue_size=K, momentum=0.9995, temperature=0.05, label_smoothing=0.0, norm_doc=False, norm_query=False,
+        moco_train_mode_encoder_k=False, weight_decay=0.01, weight_decay_from_init=False, retriever_model_id=mdir,
+        pooling="average", random_init=True, projection_size=768, optim="adamw", lr=1e-5, beta1=0.9, beta2=0.98,
+        eps=1e-6, warmup_steps=0, total_steps=100, lr_min_ratio=1.0, scheduler="linear")
+    model = moco.MoCo(opt)
+    cfg_o = O.BertShape(**BERT_BASE_UNCASED)
+    P = O.make_params(cfg_o, 93)
+    model.encoder_q.load_state_dict(P); model.encoder_k.load_state_dict(P)
+    queue = O.init_queue(768, K, 0)
+    with torch.no_grad():
+        model.queue.copy_(queue)
+    model = model.to(dev).train()
+    optimizer, scheduler = utils.set_optim(opt, model)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    st = O.MoCoState(cfg_o, P, queue, momentum=0.9995, temperature=0.05)
+    B, S = 32, 256
+    lens_q = [256, 130, 27, 256, 77, 200, 256, 64] * 4
+    lens_k = [200, 256, 64, 31, 256, 256, 130, 99] * 4
+    for step in range(3):
+        qt, qm = ragged_batch(B, S, 9500 + step, 30522, lens_q)
+        kt, km = ragged_batch(B, S, 9600 + step, 30522, lens_k)
+        loss, stats = model(qt.to(dev), qm.to(dev), kt.to(dev), km.to(dev), stats_prefix="train", iter_stats={})
+        loss.backward()
+        g_dev = torch.cat([p.grad.reshape(-1) for p in model.encoder_q.parameters()]).cpu().double()   # HF parameter order
+        optimizer.step(); scheduler.step(); model.zero_grad()
+        ref, q_ref, k_ref, rs = st.forward_backward(qt, qm, kt, km)
+        g_ref = torch.cat([st.Pq[n].grad.reshape(-1) for n, _ in O.param_names(cfg_o)]).double()
+        st.optimizer_step(1e-5)
+        got = float(loss.detach())
+        if step == 0:
+            assert float(ref) == 0.0 and got == 0.0 and float(g_dev.abs().max()) == 0.0 and float(g_ref.abs().max()) == 0.0
+        else:
+            # the loss is a difference of logits of size ~1e4 (un-normalised embeddings, T = 0.05): bf16 operands leave a few
+            # units of it; the gradient's direction is the robust quantity
+            assert abs(got - float(ref)) < 5e-2 * abs(float(ref)) + 2.0, (step, got, float(ref))
+            c = float(torch.nn.functional.cosine_similarity(g_dev, g_ref, dim=0))
+            assert c > 0.98, (step, c)
+            assert abs(float(g_dev.norm()) / float(g_ref.norm()) - 1) < 0.1
+        assert abs(float(stats["train/accuracy"][0]) - float(rs["accuracy"])) <= 100.0 / B + 1e-4
+        assert abs(float(stats["train/stdq"][0]) - float(rs["stdq"])) < 1e-2 * max(1.0, float(rs["stdq"]))
+        assert abs(float(stats["train/stdk"][0]) - float(rs["stdk"])) < 1e-2 * max(1.0, float(rs["stdk"]))
+        assert int(model.queue_ptr) == st.ptr == ((step + 1) * B) % K
+    assert float((model.queue.cpu() - st.queue).abs().max()) < 3e-2 * float(st.queue.abs().max())
