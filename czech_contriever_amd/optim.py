@@ -34,6 +34,8 @@ class FusedAdamW(torch.optim.Optimizer):
         self.grad_scale = 1.0          # e.g. 1/update_freq is NOT applied by the reference; kept at 1
         self.clip_coef = None          # device scalar set by clip_grad_norm_()
         self._pre_step = []            # callables run before the update (gradient all-reduce wait)
+        self._pre_tail = []            # callables run between the update of the matrix region and that of the vectors +
+                                       # embeddings (data parallel: the last all-reduce, 96 MB, finishes under the first update)
 
     def _moments(self, enc):
         k = id(enc)
@@ -51,7 +53,8 @@ class FusedAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
-        for fn in self._pre_step:
+        split = bool(self._pre_tail) and self.clip_coef is None      # (a clip coefficient was computed from ALL gradients)
+        for fn in (self._pre_tail if not split else []) + self._pre_step:
             fn()
         g0 = self.param_groups[0]
         self._steps += 1
@@ -62,11 +65,23 @@ class FusedAdamW(torch.optim.Optimizer):
             m, v = self._moments(enc)
             b1, b2 = g0["betas"]
             mirror = enc.mirror()
-            L.check(L.load().czc_adamw_step(
-                enc.flat_params.data_ptr(), grads.data_ptr(), m.data_ptr(), v.data_ptr(), enc.flat_params.numel(),
-                float(g0["lr"]), float(b1), float(b2), float(g0["eps"]), float(g0["weight_decay"]), self._steps,
-                float(self.grad_scale), None if self.clip_coef is None else self.clip_coef.data_ptr(),
-                mirror.data_ptr(), mirror.numel(), L.stream_ptr()))
+            n, n_mat, esz = enc.flat_params.numel(), mirror.numel(), 4
+
+            def launch(lo, hi, n_bf16):
+                L.check(L.load().czc_adamw_step(
+                    enc.flat_params.data_ptr() + lo * esz, grads.data_ptr() + lo * esz, m.data_ptr() + lo * esz,
+                    v.data_ptr() + lo * esz, hi - lo, float(g0["lr"]), float(b1), float(b2), float(g0["eps"]),
+                    float(g0["weight_decay"]), self._steps, float(self.grad_scale),
+                    None if self.clip_coef is None else self.clip_coef.data_ptr(),
+                    mirror.data_ptr(), n_bf16, L.stream_ptr()))
+
+            if split and 0 < n_mat < n and n_mat % 4 == 0:
+                launch(0, n_mat, n_mat)            # weight matrices (their all-reduces were waited for by _pre_step)
+                for fn in self._pre_tail:          # ... the vectors + embeddings slice has been averaged by now
+                    fn()
+                launch(n_mat, n, 0)
+            else:
+                launch(0, n, n_mat)
             enc.mark_mirror_fresh()
             for p in enc._plist:
                 st = self.state.get(p)
@@ -78,7 +93,7 @@ class FusedAdamW(torch.optim.Optimizer):
     # ---- gradient clipping on the flat array (train.py:314-322) ----
     @torch.no_grad()
     def clip_grad_norm_(self, max_norm):
-        for fn in self._pre_step:      # the overlapped gradient all-reduce must have finished averaging what is measured here
+        for fn in self._pre_step + self._pre_tail:   # every overlapped gradient all-reduce must have finished averaging what is measured here
             fn()
         enc = self._encoders[0]
         g = enc.flat_grads(create=False)
@@ -95,7 +110,7 @@ class FusedAdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def clip_grad_value_(self, value):
-        for fn in self._pre_step:
+        for fn in self._pre_step + self._pre_tail:
             fn()
         for enc in self._encoders:
             g = enc.flat_grads(create=False)

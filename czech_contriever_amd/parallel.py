@@ -178,7 +178,8 @@ class DataParallel(nn.Module):
         self._encoders = [m for m in module.modules() if isinstance(m, FlatBertEncoder)
                           and any(p.requires_grad for p in m._plist)]
         self._comm = None
-        self._done = None
+        self._done = None          # newest event of the communication stream (it is in order: covers every earlier range)
+        self._done_mat = None      # event behind the last WEIGHT-MATRIX range of the current backward
         self._per_tile = False
         for enc in self._encoders:
             enc._range_hooks = [self._reduce_range]
@@ -189,7 +190,13 @@ class DataParallel(nn.Module):
             self.attach(optimizer)
 
     def attach(self, optimizer):
-        optimizer._pre_step.append(self.wait)
+        """The optimizer waits for the matrix ranges before it updates the weight matrices and for the last slice (vectors +
+        embeddings, 96 MB: the one all-reduce no backward work is left to cover) only before it updates those."""
+        if self._world > 1:
+            optimizer._pre_step.append(self.wait_matrices)
+            optimizer._pre_tail.append(self.wait)
+        else:
+            optimizer._pre_step.append(self.wait)
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
@@ -209,6 +216,8 @@ class DataParallel(nn.Module):
                 average_(g, self._group)
                 self._done = torch.cuda.Event()   # the stream is in order: the newest event covers every earlier range
                 self._done.record()
+                if hi <= enc._n_mat:
+                    self._done_mat = self._done
             if not self._per_tile:
                 # The GEMMs' persistent launch sizes its grid to ALL the CUs; with RCCL's kernels holding some of them
                 # the last workgroups would start a whole pass late.  One workgroup per output tile degrades gracefully
@@ -229,3 +238,10 @@ class DataParallel(nn.Module):
         if self._done is not None:
             torch.cuda.current_stream().wait_event(self._done)
             self._done = None
+        self._done_mat = None
+
+    def wait_matrices(self):
+        """The main stream waits for the all-reduces of the weight-matrix ranges (not for the vectors + embeddings slice)."""
+        if self._done_mat is not None:
+            torch.cuda.current_stream().wait_event(self._done_mat)
+            self._done_mat = None
