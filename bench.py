@@ -371,9 +371,12 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step times (no host sync inside)
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         last = step(args.warmup + i)
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -452,6 +455,8 @@ def main():
                          "kernels": None if kernels is None else kernels[:8],
                          "hbm_kernels": None if kernels is None else [k for k in kernels if k["bound"] == "hbm"][:10],
                          "whole_step_frac": None if args.ragged else round(value * flop_per_pair / (world * PEAK_BF16_TFLOPS * 1e12), 4)},
+            "step_ms": (lambda v: {"p10": round(v[len(v) // 10], 3), "median": round(v[len(v) // 2], 3), "p90": round(v[(9 * len(v)) // 10], 3)})(
+                sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))),
             "final_loss": round(float(last.detach()), 4),
         }
         if world == 1 and not args.no_cpu_baseline and args.objective == "moco":
