@@ -30,8 +30,9 @@ reference inherits through `class Contriever(BertModel)`, src/contriever.py:11-1
   step_stats()        src/moco.py:340-351
   inbatch_loss()      src/inbatch.py:59-90 (row f4: one encoder for queries and keys, in-batch negatives)
   distill_sim_loss()  distill.py:44-47 (compute_sim_matrix) + :272-274 (mse of student vs teacher similarity matrices);
-                      distill.py itself cannot be imported here (clearml at import, Task.init at module level), so this
-                      three-line function is restated from the text: parity unpinned by the reference for row f2's loss
+                      distill.py itself cannot be imported here (clearml at import, Task.init at module level):
+                      oracle/make_golden.py compiles the text of its compute_sim_matrix function alone (ast, no
+                      stand-ins) and runs it -> tests/golden/g13_distill.npz pins this function
   warmup_linear()     src/utils.py:99-118
   adamw_step()        src/utils.py:137-150 -> torch.optim.AdamW semantics (decoupled decay)
 """
