@@ -977,6 +977,376 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const AttnArgs a
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward, sequences of at most 256 tokens, STREAMING form: one persistent workgroup per CU walks over its (batch, head)
+// items; nothing of an item is loaded or stored outside the step loop except its K / V fragments and its dK / dV tiles.
+//   * Wave w owns keys 32w .. 32w+31 (K, V fragments, dK and dV accumulators in registers) as in the fused kernel above,
+//     but in a step ALL waves work on the SAME 32-query block: Q, dO and O blocks (4 KB each) and the block's lse travel
+//     by LDS DMA through a 4-stage ring, requested three steps ahead -- across item seams too -- so the step loop never
+//     waits for HBM, and delta = rowsum(dO O) of block n+1 is taken from the ring during step n.
+//   * dQ of a block is complete after one step: each wave leaves its dS tile ([32 keys][32 queries] bf16) in a
+//     double-buffered LDS ring; in the next step wave (qh, dc) multiplies dS^T of ALL keys with its 16 columns of K (held
+//     in registers for the whole item as eight 16x16x32 operands): dQ^T[16 d][16 queries], no accumulation across steps,
+//     no fp32 dQ image in LDS (65 KB in the fused kernel), each element summed in one MFMA chain in a fixed order.  The
+//     tile goes through a 4 KB LDS image and is stored as 8-byte row pieces one step later.
+//   * The next item's K and V rows arrive by LDS DMA during this item's steps (one 1 KB piece per wave and step) in a
+//     64 KB staging area; at the seam the waves pick their fragments up from there, then the same area transposes the
+//     dK / dV tiles for row-contiguous stores and the bias-gradient column sums.
+// Counted waits only: per step every wave issues, in this order, the mask-byte load, one K/V piece and two ring pieces
+// (dummies re-fetch the last block), then at most one store; at the end of step n the ring pieces of block n+2 (issued in
+// step n-1) have at least those four operations of step n behind them: s_waitcnt vmcnt(3) (also completes the mask byte).
+// LDS: ring 4 x (Q 4096 | dO 4096 | O 4096 | raw lse 256) | lse (log2 units) 4 x 32 | delta 4 x 32 | dS 2 x 16 KB |
+//      dQ tiles 2 x 4 KB (the seam's column-sum partials reuse them) | K staging 32 KB | V staging 32 KB | sums 2 KB.
+// ---------------------------------------------------------------------------------------------
+typedef void __attribute__((address_space(3)))* att_lptr_t;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // m0 is ours to set here
+__device__ __forceinline__ void att_dma16(const void* src, unsigned char* dst) {   // 16 B per lane -> dst + 16 * lane
+  const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)(att_lptr_t)dst);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(l) : "memory", "m0");
+}
+__device__ __forceinline__ void att_dma4(const void* src, unsigned char* dst) {    // 4 B per lane -> dst + 4 * lane
+  const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)(att_lptr_t)dst);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(l) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+// The mask-byte load of the streaming kernel is inline asm as well: the compiler's wait-count pass knows nothing of the DMA
+// pieces, and for a load of its own pending across the step loop it put an s_waitcnt vmcnt(0) in front of the next write
+// to that register -- which waits for every piece just requested.  Stores stay the compiler's: it needs no wait for them,
+// and it knows their hazards (a 16-byte store wants TWO wait states before a VALU write of its data registers on gfx950:
+// with one, an asm store here lost the first dwords of lanes 12-15 of every 16 to the next address computation).
+#define ATT_BAR() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
+// 8-byte chunk swizzle of a dS tile row (key r of the tile): the 16x16x32 operand reads below and the row writes of the
+// producer are both bank-conflict free with it
+__device__ __forceinline__ int dsx(int r) { return (((r >> 3) & 1) << 2) | (((r >> 4) & 1) << 1) | ((r >> 2) & 1); }
+// 16x16x32 operand, lane (i = lane & 15, g = lane >> 4): element j = tile[8g + j][col0 + i]; tile = bf16 [32][32], 64-B rows
+__device__ __forceinline__ bf16x8 frag_ds16(const unsigned char* tile, int col0, int lane) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int row1 = 8 * g + q, row2 = row1 + 4, ch = (col0 >> 2) + p;
+  typedef s16x4 __attribute__((address_space(3)))* trp_t;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(tile + row1 * 64 + ((ch ^ dsx(row1)) << 3)));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(tile + row2 * 64 + ((ch ^ dsx(row2)) << 3)));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+// the same from a [rows][64] image (128-B rows, swz64 chunks): element j = img[row0 + 8g + j][col0 + i]
+__device__ __forceinline__ bf16x8 frag_img16(const unsigned char* img, int row0, int col0, int lane) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int row1 = row0 + 8 * g + q, row2 = row1 + 4, c = (col0 >> 3) + (p >> 1);
+  typedef s16x4 __attribute__((address_space(3)))* trp_t;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(img + row1 * 128 + ((c ^ swz64(row1)) << 4) + 8 * (p & 1)));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(img + row2 * 128 + ((c ^ swz64(row2)) << 4) + 8 * (p & 1)));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs a) {
+  constexpr int ST = 12544, O_LSE = 50176, O_DEL = 50688, O_DS = 51200, O_OUT = 83968, O_K = 92160, O_V = 124928, O_RED = 157696;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[159744];
+  // Lane-constant addresses must not be hoisted out of the loops (they were: 44 registers spilled to scratch, and scratch
+  // reloads are vector-memory operations that wait behind the DMA): every loop body starts from a laundered lane id.
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  int lane0 = threadIdx.x & 63;
+#define ATT_LANE(ln) int ln = lane0; asm volatile("" : "+v"(ln))
+  const int S = a.S, H = a.H, H3 = 3 * a.H, nh = a.nh;
+  const int nblk = (S + 31) >> 5;
+  const int G = gridDim.x;
+  const int my_items = (a.B * nh - (int)blockIdx.x + G - 1) / G;
+  const int total = my_items * nblk;
+  const float c2 = 0.125f * LOG2E;
+  const int k0 = wave * 32;
+  const bool active = k0 < S;                    // wave-uniform
+  const int qh = wave & 1, dc = wave >> 1;       // this wave's dQ^T tile: d 16dc .. +15, queries 16qh .. +15
+  const uint32_t S4 = (uint32_t)((S + 3) & ~3);
+  const uint32_t rkey = czc_rng_key(a.seed, a.site);
+  float* const lse_s = (float*)(smem + O_LSE);
+  float* const del_s = (float*)(smem + O_DEL);
+  float* const red = (float*)(smem + O_RED);      // (unused slots) | [2][64] the two query halves' dQ column sums
+  float* const redq = red + 192;
+  float* const psum = (float*)(smem + O_OUT);     // [16][128] partial column sums of the dK | dV tiles (seam only)
+
+  // ---- prefetch cursor: block pf_n of this workgroup's schedule = step pf_st of item pf_item
+  int pf_n = 0, pf_st = 0, pf_item = blockIdx.x;
+  const bf16_t *pf_q, *pf_do, *pf_o;
+  const float* pf_lse;
+  auto pf_set = [&]() {
+    const int b = pf_item / nh, hh = pf_item - b * nh;
+    pf_q = a.qkv + (size_t)b * S * H3 + hh * 64;
+    pf_do = a.dctx + (size_t)b * S * H + hh * 64;
+    pf_o = a.ctx + (size_t)b * S * H + hh * 64;
+    pf_lse = a.lse_in + ((size_t)b * nh + hh) * S;
+  };
+  pf_set();
+  auto issue_ring = [&](int lane) {   // two pieces per wave of block pf_n -> stage pf_n & 3; past the schedule's end: the last block again
+    unsigned char* stg = smem + (pf_n & 3) * ST;
+    const int qb = 32 * pf_st;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int slot = 2 * wave + j;             // 0-3 Q, 4-7 dO, 8-11 O, 12-15 lse (four times the same 256 B)
+      if (slot < 12) {
+        const int tsr = slot >> 2, p = slot & 3;
+        const int row = 8 * p + (lane >> 3), c = (lane & 7) ^ swz64(row);
+        int gr = qb + row; if (gr > S - 1) gr = S - 1;
+        const bf16_t* src = tsr == 0 ? pf_q + (size_t)gr * H3 + c * 8 : (tsr == 1 ? pf_do : pf_o) + (size_t)gr * H + c * 8;
+        att_dma16(src, stg + tsr * 4096 + p * 1024);
+      } else {
+        int gr = qb + (lane & 31); if (gr > S - 1) gr = S - 1;
+        att_dma4(pf_lse + gr, stg + 12288);
+      }
+    }
+    ++pf_n;
+    if (pf_n < total && ++pf_st == nblk) { pf_st = 0; pf_item += G; pf_set(); }
+  };
+  auto issue_kv = [&](const bf16_t* qbase, int st, int lane) {   // rows 32 st + 8 (wave & 3) .. +7 of K (waves 0-3) or V (waves 4-7) of the item at qbase
+    const int tsr = wave >> 2;
+    const int row = 32 * st + 8 * (wave & 3) + (lane >> 3), c = (lane & 7) ^ swz64(row);
+    int gr = row; if (gr > S - 1) gr = S - 1;
+    att_dma16(qbase + (size_t)gr * H3 + (tsr + 1) * H + c * 8, smem + (tsr ? O_V : O_K) + (32 * st + 8 * (wave & 3)) * 128);
+  };
+  // delta and lse (log2 units; rows past S: +1e30, their probabilities vanish) of block m, which is step st_m of its item
+  auto delta_of = [&](int m, int st_m, int lane) {
+    const unsigned char* sg = smem + (m & 3) * ST;
+    const int row = 4 * wave + (lane >> 4), q8 = lane & 15;
+    const int off = row * 128 + (((q8 >> 1) ^ swz64(row)) << 4) + 8 * (q8 & 1);
+    const uint2 x = *(const uint2*)(sg + 4096 + off), y = *(const uint2*)(sg + 8192 + off);
+    float dl = bflo(x.x) * bflo(y.x) + bfhi(x.x) * bfhi(y.x) + bflo(x.y) * bflo(y.y) + bfhi(x.y) * bfhi(y.y);
+    dl = row_sum16(dl);
+    if (q8 == 0) del_s[32 * (m & 3) + row] = dl;
+    if (q8 == 1) {
+      const float raw = ((const float*)(sg + 12288))[row];
+      lse_s[32 * (m & 3) + row] = (32 * st_m + row < S) ? raw * LOG2E : 1.0e30f;
+    }
+  };
+
+  // ---- per-item state
+  int item = blockIdx.x, b = item / nh, hh = item - b * nh;
+  bf16x8 bk[4], bv[4], kT[8];
+  float kbias = NEG_MASK;
+  auto take_fragments = [&](uint8_t kmask, int lane) {   // this wave's K / V rows and its 16 columns of K (all keys) from the staging area
+    const unsigned char* kimg = smem + O_K;
+    const unsigned char* vimg = smem + O_V;
+    if (active) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) { bk[ks] = frag_row(kimg, k0, ks, lane); bv[ks] = frag_row(vimg, k0, ks, lane); }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < nblk) kT[i] = frag_img16(kimg, 32 * i, 16 * dc, lane);
+    kbias = ((k0 + (lane & 31)) < S && kmask) ? 0.f : NEG_MASK;
+  };
+  f32x16 dk[2], dv[2];
+  f32x4 dqsum = (f32x4)(0.f);
+  dk[0] = dk[1] = dv[0] = dv[1] = (f32x16)(0.f);
+
+  // dQ^T tile of block m from the dS ring -> bf16 image m & 1 ([32 queries][64 d], 8-byte chunks XOR (query & 15))
+  auto dq_block = [&](int m, int lane) {
+    const unsigned char* dsb = smem + O_DS + (m & 1) * 16384;
+    f32x4 acc = (f32x4)(0.f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < nblk) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[i], frag_ds16(dsb + i * 2048, 16 * qh, lane), acc, 0, 0, 0);
+    acc *= 0.125f;
+    dqsum += acc;
+    const int q = 16 * qh + (lane & 15);
+    *(uint2*)(smem + O_OUT + (m & 1) * 4096 + q * 128 + (((4 * dc + (lane >> 4)) ^ (q & 15)) << 3)) =
+        make_uint2(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]));
+  };
+  auto dq_store = [&](int m, int qb, int lane) {   // image m & 1 -> dqkv rows qb .. qb+31 of the current item, 8 bytes per thread
+    const int row = 4 * wave + (lane >> 4), piece = lane & 15;
+    if (qb + row < S) {
+      const uint2 v = *(const uint2*)(smem + O_OUT + (m & 1) * 4096 + row * 128 + ((piece ^ (row & 15)) << 3));
+      *(uint2*)(a.dqkv + ((size_t)b * S + qb + row) * H3 + hh * 64 + piece * 4) = v;
+    }
+  };
+
+  // ---- prologue: the first item's K / V rows, blocks 0 .. 2, mask byte
+  {
+    ATT_LANE(lane);
+    for (int st = 0; st < nblk; ++st) issue_kv(pf_q, st, lane);
+    issue_ring(lane); issue_ring(lane); issue_ring(lane);
+    int kr = k0 + (lane & 31); if (kr > S - 1) kr = S - 1;
+    const uint8_t kmask = a.mask[(size_t)b * S + kr];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATT_BAR();
+    delta_of(0, 0, lane);
+    take_fragments(kmask, lane);
+    ATT_BAR();
+  }
+
+  int n = 0;
+#pragma unroll 1
+  for (int il = 0; il < my_items; ++il) {
+    const bool has_next = il + 1 < my_items;
+    const int nitem = has_next ? item + G : item;
+    const int nb = nitem / nh, nhh = nitem - nb * nh;
+    const bf16_t* nq = a.qkv + (size_t)nb * S * H3 + nhh * 64;
+    const uint32_t ebase0 = (uint32_t)((b * nh + hh) * S) * S4 + (uint32_t)k0;
+    uint32_t kmask_n = 0;
+#pragma unroll 1
+    for (int st = 0; st < nblk; ++st, ++n) {
+      ATT_LANE(lane);
+      const int r = lane & 31, h = lane >> 5;
+      const unsigned char* stg = smem + (n & 3) * ST;
+      const unsigned char* qt = stg;
+      const unsigned char* dot = stg + 4096;
+      const float* lse_b = lse_s + 32 * (n & 3);
+      const float* del_b = del_s + 32 * (n & 3);
+      const int qb = 32 * st;
+      {   // the next item's mask byte of this lane's key, requested in every step (the last request is the one used: a
+          // request inside a condition would make the compiler copy the register before the byte has arrived)
+        int kr = k0 + r; if (kr > S - 1) kr = S - 1;
+        asm volatile("global_load_ubyte %0, %1, off" : "=v"(kmask_n) : "v"(a.mask + (size_t)nb * S + kr) : "memory");
+      }
+      issue_kv(nq, st, lane);
+      issue_ring(lane);
+      if (st > 0) dq_block(n - 1, lane);
+      if (st > 1) dq_store(n - 2, qb - 64, lane);
+      if (active) {
+        f32x16 s = (f32x16)(0.f), dp = (f32x16)(0.f);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(qt, 0, ks, lane), bk[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(dot, 0, ks, lane), bv[ks], dp, 0, 0, 0);
+        }
+        // rows (registers) are queries qb + 8g + 4h + j, the lane is the key
+        const uint32_t ebase = ebase0 + (uint32_t)r;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 l4 = *(const f32x4*)(&lse_b[8 * g + 4 * h]);
+          const f32x4 d4 = *(const f32x4*)(&del_b[8 * g + 4 * h]);
+          const f32x4 kl = kbias - l4;
+          czc_quad qd = {0u, 0u};   // one RNG quad per lane, shared inside each group of four lanes (see the dK/dV kernel)
+          if (DROP) qd = czc_rng_quad(rkey, (ebase + (uint32_t)(qb + 8 * g + 4 * h + (r & 3)) * S4) >> 2);
+          const uint32_t qlo[4] = {quad_bcast<0>(qd.lo), quad_bcast<1>(qd.lo), quad_bcast<2>(qd.lo), quad_bcast<3>(qd.lo)};
+          const uint32_t qhi[4] = {quad_bcast<0>(qd.hi), quad_bcast<1>(qd.hi), quad_bcast<2>(qd.hi), quad_bcast<3>(qd.hi)};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(s[4 * g + j], c2, kl[j]));
+            float z = 1.f;
+            if (DROP) {
+              const uint32_t t = ((r & 2) ? qhi[j] : qlo[j]) << ((r & 1) ? 0 : 16);
+              z = t >= (a.thr << 16) ? a.inv_keep : 0.f;
+            }
+            const float dpz = z * dp[4 * g + j];
+            dp[4 * g + j] = p * (dpz - d4[j]);  // dS
+            s[4 * g + j] = p * z;               // P~
+          }
+        }
+        unsigned char* my = smem + O_DS + (n & 1) * 16384 + wave * 2048 + r * 64;
+        const int xs = dsx(r);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pf = acc_frag(s, s2), df = acc_frag(dp, s2);
+          // dS^T tile row r (this lane's key): queries 16 s2 + 4h .. +3 and 16 s2 + 8 + 4h .. +3
+          const uint4 dw = __builtin_bit_cast(uint4, df);
+          *(uint2*)(my + (((4 * s2 + h) ^ xs) << 3)) = make_uint2(dw.x, dw.y);
+          *(uint2*)(my + (((4 * s2 + 2 + h) ^ xs) << 3)) = make_uint2(dw.z, dw.w);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot, 16 * s2, 32 * dt, lane), pf, dv[dt], 0, 0, 0);
+            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 16 * s2, 32 * dt, lane), df, dk[dt], 0, 0, 0);
+          }
+        }
+      }
+      delta_of(n + 1, st + 1 == nblk ? 0 : st + 1, lane);
+      // behind block n+2's pieces: this step's mask byte, K / V piece, two ring pieces.  3, not 4: the mask byte must be in its
+      // register before the next step starts (the compiler takes that register for dead until the next request)
+      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      ATT_BAR();
+    }
+    // ---- seam: last dQ block, the next item's fragments, this item's dK / dV
+    ATT_LANE(lane);
+    const int r = lane & 31, h = lane >> 5, tid = 64 * wave + lane;
+    dq_block(n - 1, lane);
+    if (nblk > 1) dq_store(n - 2, 32 * (nblk - 2), lane);
+    {
+      f32x4 t = dqsum;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[j] = row_sum16(t[j]);
+      if ((lane & 15) == 0) *(f32x4*)(redq + 64 * qh + 16 * dc + 4 * (lane >> 4)) = t;
+      dqsum = (f32x4)(0.f);
+    }
+    asm volatile("s_waitcnt vmcnt(2)" : "+v"(kmask_n)::"memory");   // the K / V piece of the last step (two ring pieces behind it) and the mask byte before it
+    ATT_BAR();
+    dq_store(n - 1, 32 * (nblk - 1), lane);
+    // dK (x 1/8) and dV tiles -> bf16 registers; then the next item's fragments may replace K / V
+    const bool okvalid = active && (k0 + r) < S;
+    uint2 pk[8], pv[8];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float x[4], y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          x[j] = okvalid ? dk[dt][4 * g + j] * 0.125f : 0.f;
+          y[j] = okvalid ? dv[dt][4 * g + j] : 0.f;
+        }
+        pk[4 * dt + g] = make_uint2(pack2bf(x[0], x[1]), pack2bf(x[2], x[3]));
+        pv[4 * dt + g] = make_uint2(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]));
+      }
+    dk[0] = dk[1] = dv[0] = dv[1] = (f32x16)(0.f);
+    if (has_next) take_fragments((uint8_t)(kmask_n & 0xffu), lane);
+    ATT_BAR();
+    // bf16 [256 keys][64] images in the staging area (a lane owns a row; keys past S are zeros)
+    {
+      unsigned char* rk = smem + O_K + (k0 + r) * 128;
+      unsigned char* rv = smem + O_V + (k0 + r) * 128;
+      const int sw = swz64(k0 + r);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int off = ((c ^ sw) << 4) + 8 * h;
+        *(uint2*)(rk + off) = pk[c];
+        *(uint2*)(rv + off) = pv[c];
+      }
+    }
+    ATT_BAR();
+    {
+      const int row = tid >> 1, half = tid & 1;
+      if (row < S) {
+        bf16_t* dstk = a.dqkv + ((size_t)b * S + row) * H3 + H + hh * 64 + 32 * half;
+        bf16_t* dstv = dstk + H;
+        const int sw = swz64(row);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int off = row * 128 + (((4 * half + c) ^ sw) << 4);
+          *(uint4*)(dstk + 8 * c) = *(const uint4*)(smem + O_K + off);
+          *(uint4*)(dstv + 8 * c) = *(const uint4*)(smem + O_V + off);
+        }
+      }
+      if (a.dbias) {
+        const int quad = tid & 31, grp = tid >> 5;      // 32 column quads (dK | dV) x 16 groups of 16 rows
+        const unsigned char* img = smem + (quad < 16 ? O_K : O_V);
+        const int q4 = quad & 15;
+        f32x4 sk = (f32x4)(0.f);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int rw = 16 * grp + i;
+          const uint2 w = *(const uint2*)(img + rw * 128 + (((q4 >> 1) ^ swz64(rw)) << 4) + 8 * (q4 & 1));
+          sk += (f32x4){bflo(w.x), bfhi(w.x), bflo(w.y), bfhi(w.y)};
+        }
+        *(f32x4*)(psum + grp * 128 + 4 * quad) = sk;
+      }
+    }
+    ATT_BAR();
+    if (a.dbias && tid < 192) {
+      float t;
+      if (tid < 64) t = redq[tid] + redq[64 + tid];
+      else {
+        t = 0.f;
+#pragma unroll
+        for (int gq = 0; gq < 16; ++gq) t += psum[gq * 128 + tid - 64];
+      }
+      a.dbias[(size_t)b * H3 + (tid >> 6) * H + hh * 64 + (tid & 63)] = t;
+    }
+    item = nitem; b = nb; hh = nhh;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // dummy ring pieces may still be on their way into this workgroup's LDS
+#undef ATT_LANE
+}
+
 static int attn_check(const char* who, int B, int S, int nh, float p) {
   CZC_REQUIRE(B > 0 && S > 0 && S <= 512 && nh > 0, "%s: batch=%d seq=%d heads=%d (seq <= 512)", who, B, S, nh);
   CZC_REQUIRE(p >= 0.f && p < 1.f, "%s: dropout_p=%f", who, p);
@@ -988,6 +1358,7 @@ static int attn_check(const char* who, int B, int S, int nh, float p) {
 
 using namespace czc;
 
+static int g_attn_stream_bwd = -1;  // CZC_ATTN_STREAM_BWD=0: the one-workgroup-per-item fused backward instead of the streaming one (A/B runs)
 static int g_attn_fused_bwd = -1;   // CZC_ATTN_FUSED_BWD=0 keeps the two-kernel backward for short sequences too (A/B runs)
 
 extern "C" int64_t czc_attention_bias_scratch_floats(int batch, int seq, int heads) {
@@ -1035,6 +1406,22 @@ extern "C" int czc_attention_backward(const uint16_t* qkv, const uint8_t* mask, 
   a.seed = seed; a.site = site;
   hipStream_t st = (hipStream_t)stream;
   if (g_attn_fused_bwd < 0) { const char* e = getenv("CZC_ATTN_FUSED_BWD"); g_attn_fused_bwd = (e && e[0] == '0') ? 0 : 1; }
+  if (g_attn_stream_bwd < 0) { const char* e = getenv("CZC_ATTN_STREAM_BWD"); g_attn_stream_bwd = (e && e[0] == '0') ? 0 : 1; }
+  if (seq <= 256 && g_attn_fused_bwd && g_attn_stream_bwd) {   // persistent workgroups, operands streamed through LDS
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      CZC_HIP(hipGetDevice(&dev));
+      CZC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const int items = batch * heads;
+    dim3 gridp(items < cus ? items : cus);
+    if (a.thr) hipLaunchKernelGGL(attn_bwd_stream_kernel<true>, gridp, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL(attn_bwd_stream_kernel<false>, gridp, dim3(512), 0, st, a);
+    CZC_LAUNCH_CHECK();
+    if (d_bias_qkv) return czc_reduce_partials(partials, batch, 3 * a.H, 3 * a.H, d_bias_qkv, stream);
+    return CZC_OK;
+  }
   if (seq <= 256 && g_attn_fused_bwd) {   // one pass over the scores for dQ, dK and dV
     dim3 grid1(1, heads, batch);
 
