@@ -1105,6 +1105,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
     int gr = row; if (gr > S - 1) gr = S - 1;
     att_dma16(qbase + (size_t)gr * H3 + (tsr + 1) * H + c * 8, smem + (tsr ? O_V : O_K) + (32 * st + 8 * (wave & 3)) * 128);
   };
+  auto issue_kv64 = [&](const bf16_t* qbase, int grp, int lane) {   // rows 64 grp .. +63 of K (waves 0-3) and V (waves 4-7): two pieces per wave
+    const int tsr = wave >> 2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r0 = 64 * grp + 16 * (wave & 3) + 8 * j;
+      const int row = r0 + (lane >> 3), c = (lane & 7) ^ swz64(row);
+      int gr = row; if (gr > S - 1) gr = S - 1;
+      att_dma16(qbase + (size_t)gr * H3 + (tsr + 1) * H + c * 8, smem + (tsr ? O_V : O_K) + r0 * 128);
+    }
+  };
   // delta and lse (log2 units; rows past S: +1e30, their probabilities vanish) of block m, which is step st_m of its item
   auto delta_of = [&](int m, int st_m, int lane) {
     const unsigned char* sg = smem + (m & 3) * ST;
@@ -1120,6 +1130,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
     }
   };
 
+#ifdef ATT_STAMPS   // diagnostic build only (tools/stamp_attn.py): s_memtime of wave 0 / lane 0 at fixed points of the second item
+  unsigned long long* const stamp_buf = (unsigned long long*)a.delta + 128 * blockIdx.x;
+  int stamp_on = 0;
+#define ATT_STAMP(k) do { if (stamp_on && wave == ATT_STAMPS && lane0 == 0) { stamp_buf[k] = __builtin_amdgcn_s_memtime(); if ((k) == 0 || (k) == 65) stamp_buf[66 + ((k) != 0)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define ATT_STAMP(k) do { } while (0)
+#endif
   // ---- per-item state
   int item = blockIdx.x, b = item / nh, hh = item - b * nh;
   bf16x8 bk[4], bv[4], kT[8];
@@ -1143,11 +1160,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
   // dQ^T tile of block m from the dS ring -> bf16 image m & 1 ([32 queries][64 d], 8-byte chunks XOR (query & 15))
   auto dq_block = [&](int m, int lane) {
     const unsigned char* dsb = smem + O_DS + (m & 1) * 16384;
-    f32x4 acc = (f32x4)(0.f);
+    f32x4 acc = (f32x4)(0.f), acc1 = (f32x4)(0.f);   // two chains (even / odd key tiles): half the dependent-MFMA latency
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 8; i += 2) {
       if (i < nblk) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[i], frag_ds16(dsb + i * 2048, 16 * qh, lane), acc, 0, 0, 0);
-    acc *= 0.125f;
+      if (i + 1 < nblk) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[i + 1], frag_ds16(dsb + (i + 1) * 2048, 16 * qh, lane), acc1, 0, 0, 0);
+    }
+    acc = (acc + acc1) * 0.125f;
     dqsum += acc;
     const int q = 16 * qh + (lane & 15);
     *(uint2*)(smem + O_OUT + (m & 1) * 4096 + q * 128 + (((4 * dc + (lane >> 4)) ^ (q & 15)) << 3)) =
@@ -1175,6 +1194,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
     ATT_BAR();
   }
 
+  // With more than one step per item the dK / dV rows of an item leave during the NEXT item's steps (64 rows of each per
+  // step, read from the images the seam left in the staging area), and the K / V rows of the item after that arrive in the
+  // 64 rows freed one step earlier: a seam that stored them itself spent 9.7k of an item's 69k cycles issuing stores.
+  const bool defer = nblk > 1;
+  int pend_b = 0, pend_hh = 0;
+  bool pending = false;
   int n = 0;
 #pragma unroll 1
   for (int il = 0; il < my_items; ++il) {
@@ -1184,6 +1209,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
     const bf16_t* nq = a.qkv + (size_t)nb * S * H3 + nhh * 64;
     const uint32_t ebase0 = (uint32_t)((b * nh + hh) * S) * S4 + (uint32_t)k0;
     uint32_t kmask_n = 0;
+#ifdef ATT_STAMPS
+    stamp_on = il == 1;
+#endif
+    ATT_STAMP(0);
 #pragma unroll 1
     for (int st = 0; st < nblk; ++st, ++n) {
       ATT_LANE(lane);
@@ -1199,10 +1228,22 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
         int kr = k0 + r; if (kr > S - 1) kr = S - 1;
         asm volatile("global_load_ubyte %0, %1, off" : "=v"(kmask_n) : "v"(a.mask + (size_t)nb * S + kr) : "memory");
       }
-      issue_kv(nq, st, lane);
+      if (!defer) issue_kv(nq, st, lane);
+      else if (st >= 1 && 2 * (st - 1) < nblk) issue_kv64(nq, st - 1, lane);
       issue_ring(lane);
+      ATT_STAMP(1 + 6 * st);
       if (st > 0) dq_block(n - 1, lane);
       if (st > 1) dq_store(n - 2, qb - 64, lane);
+      if (pending && 2 * st < nblk) {   // rows 64 st .. +63 of the previous item's dK and dV
+        const int tid = 64 * wave + lane, row = 64 * st + (tid >> 3), c = tid & 7;
+        if (row < S) {
+          const int off = row * 128 + ((c ^ swz64(row)) << 4);
+          bf16_t* dstk = a.dqkv + ((size_t)pend_b * S + row) * H3 + H + pend_hh * 64 + 8 * c;
+          *(uint4*)dstk = *(const uint4*)(smem + O_K + off);
+          *(uint4*)(dstk + H) = *(const uint4*)(smem + O_V + off);
+        }
+      }
+      ATT_STAMP(2 + 6 * st);
       if (active) {
         f32x16 s = (f32x16)(0.f), dp = (f32x16)(0.f);
 #pragma unroll
@@ -1250,11 +1291,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
           }
         }
       }
+      ATT_STAMP(3 + 6 * st);
       delta_of(n + 1, st + 1 == nblk ? 0 : st + 1, lane);
+      ATT_STAMP(4 + 6 * st);
       // behind block n+2's pieces: this step's mask byte, K / V piece, two ring pieces.  3, not 4: the mask byte must be in its
       // register before the next step starts (the compiler takes that register for dead until the next request)
       asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      ATT_STAMP(5 + 6 * st);
       ATT_BAR();
+      ATT_STAMP(6 + 6 * st);
     }
     // ---- seam: last dQ block, the next item's fragments, this item's dK / dV
     ATT_LANE(lane);
@@ -1268,8 +1313,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
       if ((lane & 15) == 0) *(f32x4*)(redq + 64 * qh + 16 * dc + 4 * (lane >> 4)) = t;
       dqsum = (f32x4)(0.f);
     }
+    ATT_STAMP(60);
     asm volatile("s_waitcnt vmcnt(2)" : "+v"(kmask_n)::"memory");   // the K / V piece of the last step (two ring pieces behind it) and the mask byte before it
     ATT_BAR();
+    ATT_STAMP(61);
     dq_store(n - 1, 32 * (nblk - 1), lane);
     // dK (x 1/8) and dV tiles -> bf16 registers; then the next item's fragments may replace K / V
     const bool okvalid = active && (k0 + r) < S;
@@ -1290,6 +1337,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
     dk[0] = dk[1] = dv[0] = dv[1] = (f32x16)(0.f);
     if (has_next) take_fragments((uint8_t)(kmask_n & 0xffu), lane);
     ATT_BAR();
+    ATT_STAMP(62);
     // bf16 [256 keys][64] images in the staging area (a lane owns a row; keys past S are zeros)
     {
       unsigned char* rk = smem + O_K + (k0 + r) * 128;
@@ -1303,9 +1351,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
       }
     }
     ATT_BAR();
+    ATT_STAMP(63);
+    pending = defer && has_next;
+    pend_b = b; pend_hh = hh;
     {
       const int row = tid >> 1, half = tid & 1;
-      if (row < S) {
+      if (!pending && row < S) {
         bf16_t* dstk = a.dqkv + ((size_t)b * S + row) * H3 + H + hh * 64 + 32 * half;
         bf16_t* dstv = dstk + H;
         const int sw = swz64(row);
@@ -1331,6 +1382,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
       }
     }
     ATT_BAR();
+    ATT_STAMP(64);
     if (a.dbias && tid < 192) {
       float t;
       if (tid < 64) t = redq[tid] + redq[64 + tid];
@@ -1342,9 +1394,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
       a.dbias[(size_t)b * H3 + (tid >> 6) * H + hh * 64 + (tid & 63)] = t;
     }
     item = nitem; b = nb; hh = nhh;
+    ATT_STAMP(65);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // dummy ring pieces may still be on their way into this workgroup's LDS
 #undef ATT_LANE
+#undef ATT_STAMP
 }
 
 static int attn_check(const char* who, int B, int S, int nh, float p) {
