@@ -992,9 +992,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const AttnArgs a
 //   * The next item's K and V rows arrive by LDS DMA during this item's steps (one 1 KB piece per wave and step) in a
 //     64 KB staging area; at the seam the waves pick their fragments up from there, then the same area transposes the
 //     dK / dV tiles for row-contiguous stores and the bias-gradient column sums.
-// Counted waits only: per step every wave issues, in this order, the mask-byte load, one K/V piece and two ring pieces
-// (dummies re-fetch the last block), then at most one store; at the end of step n the ring pieces of block n+2 (issued in
-// step n-1) have at least those four operations of step n behind them: s_waitcnt vmcnt(3) (also completes the mask byte).
+// Counted waits only: per step a wave issues, in this order, its K / V pieces, its ring
+// pieces (two for waves 0-5, the lse piece for wave 6, none for wave 7; past the schedule's end they re-fetch the last
+// block), then stores; at the end of step n its ring pieces of block n+2 (issued in step n-1) have at least the ring pieces
+// of step n behind them: s_waitcnt vmcnt(2) / vmcnt(1).
 // LDS: ring 4 x (Q 4096 | dO 4096 | O 4096 | raw lse 256) | lse (log2 units) 4 x 32 | delta 4 x 32 | dS 2 x 16 KB |
 //      dQ tiles 2 x 4 KB (the seam's column-sum partials reuse them) | K staging 32 KB | V staging 32 KB | sums 2 KB.
 // ---------------------------------------------------------------------------------------------
@@ -1008,6 +1009,16 @@ __device__ __forceinline__ void att_dma16(const void* src, unsigned char* dst) {
 __device__ __forceinline__ void att_dma4(const void* src, unsigned char* dst) {    // 4 B per lane -> dst + 4 * lane
   const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)(att_lptr_t)dst);
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(l) : "memory", "m0");
+}
+// the same from a wave-uniform 64-bit base (scalar registers) plus a 32-bit per-lane byte offset: the lane part of a piece's
+// address never changes, so the step loop spends scalar adds on addresses instead of 64-bit vector arithmetic
+__device__ __forceinline__ void att_dma16_s(unsigned off, const void* base, unsigned char* dst) {
+  const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)(att_lptr_t)dst);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(l) : "memory", "m0");
+}
+__device__ __forceinline__ void att_dma4_s(unsigned off, const void* base, unsigned char* dst) {
+  const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)(att_lptr_t)dst);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(off), "s"(base), "s"(l) : "memory", "m0");
 }
 #pragma clang diagnostic pop
 // The mask-byte load of the streaming kernel is inline asm as well: the compiler's wait-count pass knows nothing of the DMA
@@ -1079,12 +1090,42 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
     pf_lse = a.lse_in + ((size_t)b * nh + hh) * S;
   };
   pf_set();
+  // Lane parts of the DMA source addresses, computed once on purpose (six registers): byte offsets of this lane's 16 bytes
+  // inside a 32-row block (ring pieces; slot 2 wave + j) and inside a 64-row group (K / V pieces), for rows that need no
+  // clamping to S - 1.  Blocks and groups that reach past S take the general path below.
+  unsigned ring_off[2], kv_off[2];
+  {
+    const int lane = lane0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int slot = 2 * wave + j, tsr = slot >> 2, p = slot & 3;
+      const int row = 8 * p + (lane >> 3), c = (lane & 7) ^ swz64(row);
+      ring_off[j] = slot < 12 ? (unsigned)((row * (tsr == 0 ? H3 : H) + c * 8) * 2) : (unsigned)((lane & 31) * 4);
+      const int rk = 16 * (wave & 3) + 8 * j + (lane >> 3), ck = (lane & 7) ^ swz64(rk);
+      kv_off[j] = (unsigned)((rk * H3 + ck * 8) * 2);
+    }
+  }
+  unsigned kr_off;   // this lane's key, clamped to S - 1: offset of its mask byte in a batch row
+  { int kr = k0 + (lane0 & 31); if (kr > S - 1) kr = S - 1; kr_off = (unsigned)kr; }
   auto issue_ring = [&](int lane) {   // two pieces per wave of block pf_n -> stage pf_n & 3; past the schedule's end: the last block again
     unsigned char* stg = smem + (pf_n & 3) * ST;
     const int qb = 32 * pf_st;
+    if (qb + 32 <= S) {   // no row of the block is clamped: scalar bases + the precomputed lane offsets
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int slot = 2 * wave + j, tsr = slot >> 2, p = slot & 3;
+        if (slot < 12) {
+          const bf16_t* base = tsr == 0 ? pf_q + (size_t)qb * H3 : (tsr == 1 ? pf_do : pf_o) + (size_t)qb * H;
+          att_dma16_s(ring_off[j], base, stg + tsr * 4096 + p * 1024);
+        } else if (slot == 12) {
+          att_dma4_s(ring_off[j], pf_lse + qb, stg + 12288);
+        }
+      }
+    } else
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int slot = 2 * wave + j;             // 0-3 Q, 4-7 dO, 8-11 O, 12-15 lse (four times the same 256 B)
+      const int slot = 2 * wave + j;             // 0-3 Q, 4-7 dO, 8-11 O (waves 0-5), 12 lse (wave 6); wave 7 has no ring piece
+      if (slot > 12) continue;
       if (slot < 12) {
         const int tsr = slot >> 2, p = slot & 3;
         const int row = 8 * p + (lane >> 3), c = (lane & 7) ^ swz64(row);
@@ -1107,6 +1148,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
   };
   auto issue_kv64 = [&](const bf16_t* qbase, int grp, int lane) {   // rows 64 grp .. +63 of K (waves 0-3) and V (waves 4-7): two pieces per wave
     const int tsr = wave >> 2;
+    if (64 * grp + 64 <= S) {
+      const bf16_t* base = qbase + (size_t)(64 * grp) * H3 + (tsr + 1) * H;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) att_dma16_s(kv_off[j], base, smem + (tsr ? O_V : O_K) + (64 * grp + 16 * (wave & 3) + 8 * j) * 128);
+    } else
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r0 = 64 * grp + 16 * (wave & 3) + 8 * j;
@@ -1208,7 +1254,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
     const int nb = nitem / nh, nhh = nitem - nb * nh;
     const bf16_t* nq = a.qkv + (size_t)nb * S * H3 + nhh * 64;
     const uint32_t ebase0 = (uint32_t)((b * nh + hh) * S) * S4 + (uint32_t)k0;
-    uint32_t kmask_n = 0;
 #ifdef ATT_STAMPS
     stamp_on = il == 1;
 #endif
@@ -1223,11 +1268,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
       const float* lse_b = lse_s + 32 * (n & 3);
       const float* del_b = del_s + 32 * (n & 3);
       const int qb = 32 * st;
-      {   // the next item's mask byte of this lane's key, requested in every step (the last request is the one used: a
-          // request inside a condition would make the compiler copy the register before the byte has arrived)
-        int kr = k0 + r; if (kr > S - 1) kr = S - 1;
-        asm volatile("global_load_ubyte %0, %1, off" : "=v"(kmask_n) : "v"(a.mask + (size_t)nb * S + kr) : "memory");
-      }
       if (!defer) issue_kv(nq, st, lane);
       else if (st >= 1 && 2 * (st - 1) < nblk) issue_kv64(nq, st - 1, lane);
       issue_ring(lane);
@@ -1294,9 +1334,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
       ATT_STAMP(3 + 6 * st);
       delta_of(n + 1, st + 1 == nblk ? 0 : st + 1, lane);
       ATT_STAMP(4 + 6 * st);
-      // behind block n+2's pieces: this step's mask byte, K / V piece, two ring pieces.  3, not 4: the mask byte must be in its
-      // register before the next step starts (the compiler takes that register for dead until the next request)
-      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      // behind a wave's pieces of block n+2 (requested in step n-1) are at least its pieces of block n+3: two (waves 0-5),
+      // one (wave 6: lse); wave 7 has no ring piece
+      if (wave < 6) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if (wave == 6) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
       ATT_STAMP(5 + 6 * st);
       ATT_BAR();
       ATT_STAMP(6 + 6 * st);
@@ -1304,6 +1345,25 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
     // ---- seam: last dQ block, the next item's fragments, this item's dK / dV
     ATT_LANE(lane);
     const int r = lane & 31, h = lane >> 5, tid = 64 * wave + lane;
+    // The next item's mask bytes of this wave's 32 keys: one scalar load of 32 bytes, waited for on the spot (a vector
+    // load here would be the compiler's, and its wait-count pass, which knows nothing of the DMA pieces in flight, would
+    // wait for all of them; an asm vector load hands the compiler a register it believes valid before the byte arrives).
+    // Waves whose keys reach past S or whose bytes are not dword-aligned read their byte the plain way.
+    uint32_t kmask_n = 0;
+    {
+      const uint8_t* mrow = a.mask + (size_t)nb * S;
+      if (k0 + 32 <= S && (((__UINTPTR_TYPE__)(mrow + k0)) & 3) == 0) {
+        typedef unsigned u32x8_t __attribute__((ext_vector_type(8)));
+        u32x8_t mw;
+        asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mw) : "s"(mrow + k0) : "memory");
+        const uint32_t a0 = (r & 4) ? mw[1] : mw[0], a1 = (r & 4) ? mw[3] : mw[2], a2 = (r & 4) ? mw[5] : mw[4], a3 = (r & 4) ? mw[7] : mw[6];
+        const uint32_t b0 = (r & 8) ? a1 : a0, b1 = (r & 8) ? a3 : a2;
+        kmask_n = (((r & 16) ? b1 : b0) >> (8 * (r & 3))) & 0xffu;
+      } else if (active) {
+        kmask_n = mrow[kr_off];
+        asm volatile("" : "+v"(kmask_n));   // used here: the compiler waits for its load now, nothing of it stays pending into the loops
+      }
+    }
     dq_block(n - 1, lane);
     if (nblk > 1) dq_store(n - 2, 32 * (nblk - 2), lane);
     {
@@ -1314,7 +1374,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
       dqsum = (f32x4)(0.f);
     }
     ATT_STAMP(60);
-    asm volatile("s_waitcnt vmcnt(2)" : "+v"(kmask_n)::"memory");   // the K / V piece of the last step (two ring pieces behind it) and the mask byte before it
+    // the K / V pieces of the next item: only the last step's ring pieces are behind them for sure
+    if (wave < 6) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ATT_BAR();
     ATT_STAMP(61);
     dq_store(n - 1, 32 * (nblk - 1), lane);
