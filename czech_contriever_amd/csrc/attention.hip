@@ -1002,22 +1002,22 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const AttnArgs a
 typedef void __attribute__((address_space(3)))* att_lptr_t;
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"   // m0 is ours to set here
-__device__ __forceinline__ void att_dma16(const void* src, unsigned char* dst) {   // 16 B per lane -> dst + 16 * lane
-  const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)(att_lptr_t)dst);
+__device__ __forceinline__ void att_dma16(const void* src, unsigned dst) {   // 16 B per lane -> dst + 16 * lane
+  const unsigned l = __builtin_amdgcn_readfirstlane(dst);   // LDS byte address (wave-uniform)
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(l) : "memory", "m0");
 }
-__device__ __forceinline__ void att_dma4(const void* src, unsigned char* dst) {    // 4 B per lane -> dst + 4 * lane
-  const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)(att_lptr_t)dst);
+__device__ __forceinline__ void att_dma4(const void* src, unsigned dst) {    // 4 B per lane -> dst + 4 * lane
+  const unsigned l = __builtin_amdgcn_readfirstlane(dst);   // LDS byte address (wave-uniform)
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(l) : "memory", "m0");
 }
 // the same from a wave-uniform 64-bit base (scalar registers) plus a 32-bit per-lane byte offset: the lane part of a piece's
 // address never changes, so the step loop spends scalar adds on addresses instead of 64-bit vector arithmetic
-__device__ __forceinline__ void att_dma16_s(unsigned off, const void* base, unsigned char* dst) {
-  const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)(att_lptr_t)dst);
+__device__ __forceinline__ void att_dma16_s(unsigned off, const void* base, unsigned dst) {
+  const unsigned l = __builtin_amdgcn_readfirstlane(dst);   // LDS byte address (wave-uniform)
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(l) : "memory", "m0");
 }
-__device__ __forceinline__ void att_dma4_s(unsigned off, const void* base, unsigned char* dst) {
-  const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)(att_lptr_t)dst);
+__device__ __forceinline__ void att_dma4_s(unsigned off, const void* base, unsigned dst) {
+  const unsigned l = __builtin_amdgcn_readfirstlane(dst);   // LDS byte address (wave-uniform)
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(off), "s"(base), "s"(l) : "memory", "m0");
 }
 #pragma clang diagnostic pop
@@ -1052,23 +1052,28 @@ __device__ __forceinline__ bf16x8 frag_img16(const unsigned char* img, int row0,
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <bool DROP>
+// FULL: the sequence is exactly 256 tokens (the headline shape): every wave is active, no row index is clamped, the block
+// count is a constant -- the wave-uniform branches that guard those cases split the step into many basic blocks, and the
+// compiler schedules inside a block only; without them the dQ chain and the delta chain sit in ONE block with the softmax
+// arithmetic and their LDS / MFMA latencies run under it.
+template <bool DROP, bool FULL>
 __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs a) {
   constexpr int ST = 12544, O_LSE = 50176, O_DEL = 50688, O_DS = 51200, O_OUT = 83968, O_K = 92160, O_V = 124928, O_RED = 157696;
   __shared__ __attribute__((aligned(16))) unsigned char smem[159744];
+  const unsigned smem_lds = (unsigned)(__UINTPTR_TYPE__)(att_lptr_t)smem;   // DMA destinations are LDS byte addresses
   // Lane-constant addresses must not be hoisted out of the loops (they were: 44 registers spilled to scratch, and scratch
   // reloads are vector-memory operations that wait behind the DMA): every loop body starts from a laundered lane id.
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   int lane0 = threadIdx.x & 63;
 #define ATT_LANE(ln) int ln = lane0; asm volatile("" : "+v"(ln))
-  const int S = a.S, H = a.H, H3 = 3 * a.H, nh = a.nh;
-  const int nblk = (S + 31) >> 5;
+  const int S = FULL ? 256 : a.S, H = a.H, H3 = 3 * a.H, nh = a.nh;
+  const int nblk = FULL ? 8 : (S + 31) >> 5;
   const int G = gridDim.x;
   const int my_items = (a.B * nh - (int)blockIdx.x + G - 1) / G;
   const int total = my_items * nblk;
   const float c2 = 0.125f * LOG2E;
   const int k0 = wave * 32;
-  const bool active = k0 < S;                    // wave-uniform
+  const bool active = FULL || k0 < S;            // wave-uniform
   const int qh = wave & 1, dc = wave >> 1;       // this wave's dQ^T tile: d 16dc .. +15, queries 16qh .. +15
   const uint32_t S4 = (uint32_t)((S + 3) & ~3);
   const uint32_t rkey = czc_rng_key(a.seed, a.site);
@@ -1108,9 +1113,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
   unsigned kr_off;   // this lane's key, clamped to S - 1: offset of its mask byte in a batch row
   { int kr = k0 + (lane0 & 31); if (kr > S - 1) kr = S - 1; kr_off = (unsigned)kr; }
   auto issue_ring = [&](int lane) {   // two pieces per wave of block pf_n -> stage pf_n & 3; past the schedule's end: the last block again
-    unsigned char* stg = smem + (pf_n & 3) * ST;
+    const unsigned stg = smem_lds + (pf_n & 3) * ST;
     const int qb = 32 * pf_st;
-    if (qb + 32 <= S) {   // no row of the block is clamped: scalar bases + the precomputed lane offsets
+    if (FULL || qb + 32 <= S) {   // no row of the block is clamped: scalar bases + the precomputed lane offsets
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int slot = 2 * wave + j, tsr = slot >> 2, p = slot & 3;
@@ -1144,21 +1149,21 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
     const int tsr = wave >> 2;
     const int row = 32 * st + 8 * (wave & 3) + (lane >> 3), c = (lane & 7) ^ swz64(row);
     int gr = row; if (gr > S - 1) gr = S - 1;
-    att_dma16(qbase + (size_t)gr * H3 + (tsr + 1) * H + c * 8, smem + (tsr ? O_V : O_K) + (32 * st + 8 * (wave & 3)) * 128);
+    att_dma16(qbase + (size_t)gr * H3 + (tsr + 1) * H + c * 8, smem_lds + (tsr ? O_V : O_K) + (32 * st + 8 * (wave & 3)) * 128);
   };
   auto issue_kv64 = [&](const bf16_t* qbase, int grp, int lane) {   // rows 64 grp .. +63 of K (waves 0-3) and V (waves 4-7): two pieces per wave
     const int tsr = wave >> 2;
-    if (64 * grp + 64 <= S) {
+    if (FULL || 64 * grp + 64 <= S) {
       const bf16_t* base = qbase + (size_t)(64 * grp) * H3 + (tsr + 1) * H;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) att_dma16_s(kv_off[j], base, smem + (tsr ? O_V : O_K) + (64 * grp + 16 * (wave & 3) + 8 * j) * 128);
+      for (int j = 0; j < 2; ++j) att_dma16_s(kv_off[j], base, smem_lds + (tsr ? O_V : O_K) + (64 * grp + 16 * (wave & 3) + 8 * j) * 128);
     } else
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r0 = 64 * grp + 16 * (wave & 3) + 8 * j;
       const int row = r0 + (lane >> 3), c = (lane & 7) ^ swz64(row);
       int gr = row; if (gr > S - 1) gr = S - 1;
-      att_dma16(qbase + (size_t)gr * H3 + (tsr + 1) * H + c * 8, smem + (tsr ? O_V : O_K) + r0 * 128);
+      att_dma16(qbase + (size_t)gr * H3 + (tsr + 1) * H + c * 8, smem_lds + (tsr ? O_V : O_K) + r0 * 128);
     }
   };
   // delta and lse (log2 units; rows past S: +1e30, their probabilities vanish) of block m, which is step st_m of its item
@@ -1169,6 +1174,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
     const uint2 x = *(const uint2*)(sg + 4096 + off), y = *(const uint2*)(sg + 8192 + off);
     float dl = bflo(x.x) * bflo(y.x) + bfhi(x.x) * bfhi(y.x) + bflo(x.y) * bflo(y.y) + bfhi(x.y) * bfhi(y.y);
     dl = row_sum16(dl);
+    if (FULL) {   // all sixteen lanes of a row hold the same two values: they all write them (no divergent branch)
+      del_s[32 * (m & 3) + row] = dl;
+      lse_s[32 * (m & 3) + row] = ((const float*)(sg + 12288))[row] * LOG2E;
+      return;
+    }
     if (q8 == 0) del_s[32 * (m & 3) + row] = dl;
     if (q8 == 1) {
       const float raw = ((const float*)(sg + 12288))[row];
@@ -1196,7 +1206,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      if (i < nblk) kT[i] = frag_img16(kimg, 32 * i, 16 * dc, lane);
+      if (FULL || i < nblk) kT[i] = frag_img16(kimg, 32 * i, 16 * dc, lane);
     kbias = ((k0 + (lane & 31)) < S && kmask) ? 0.f : NEG_MASK;
   };
   f32x16 dk[2], dv[2];
@@ -1204,15 +1214,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
   dk[0] = dk[1] = dv[0] = dv[1] = (f32x16)(0.f);
 
   // dQ^T tile of block m from the dS ring -> bf16 image m & 1 ([32 queries][64 d], 8-byte chunks XOR (query & 15))
-  auto dq_block = [&](int m, int lane) {
+  auto dq_block = [&](int m, int lane, bool live = true) {   // live = false (FULL, first step of an item): nothing is there yet, the tile is zeros
     const unsigned char* dsb = smem + O_DS + (m & 1) * 16384;
     f32x4 acc = (f32x4)(0.f), acc1 = (f32x4)(0.f);   // two chains (even / odd key tiles): half the dependent-MFMA latency
 #pragma unroll
     for (int i = 0; i < 8; i += 2) {
-      if (i < nblk) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[i], frag_ds16(dsb + i * 2048, 16 * qh, lane), acc, 0, 0, 0);
-      if (i + 1 < nblk) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[i + 1], frag_ds16(dsb + (i + 1) * 2048, 16 * qh, lane), acc1, 0, 0, 0);
+      if (FULL || i < nblk) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[i], frag_ds16(dsb + i * 2048, 16 * qh, lane), acc, 0, 0, 0);
+      if (FULL || i + 1 < nblk) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[i + 1], frag_ds16(dsb + (i + 1) * 2048, 16 * qh, lane), acc1, 0, 0, 0);
     }
     acc = (acc + acc1) * 0.125f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = live ? acc[j] : 0.f;
     dqsum += acc;
     const int q = 16 * qh + (lane & 15);
     *(uint2*)(smem + O_OUT + (m & 1) * 4096 + q * 128 + (((4 * dc + (lane >> 4)) ^ (q & 15)) << 3)) =
@@ -1272,7 +1284,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
       else if (st >= 1 && 2 * (st - 1) < nblk) issue_kv64(nq, st - 1, lane);
       issue_ring(lane);
       ATT_STAMP(1 + 6 * st);
-      if (st > 0) dq_block(n - 1, lane);
+      if (!FULL && st > 0) dq_block(n - 1, lane);
       if (st > 1) dq_store(n - 2, qb - 64, lane);
       if (pending && 2 * st < nblk) {   // rows 64 st .. +63 of the previous item's dK and dV
         const int tid = 64 * wave + lane, row = 64 * st + (tid >> 3), c = tid & 7;
@@ -1290,6 +1302,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
         for (int ks = 0; ks < 4; ++ks) {
           s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(qt, 0, ks, lane), bk[ks], s, 0, 0, 0);
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(dot, 0, ks, lane), bv[ks], dp, 0, 0, 0);
+        }
+        if (FULL) {   // the two short chains in the same basic block as the softmax arithmetic
+          dq_block(n - 1, lane, st > 0);
+          delta_of(n + 1, st + 1 == nblk ? 0 : st + 1, lane);
         }
         // rows (registers) are queries qb + 8g + 4h + j, the lane is the key
         const uint32_t ebase = ebase0 + (uint32_t)r;
@@ -1332,7 +1348,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
         }
       }
       ATT_STAMP(3 + 6 * st);
-      delta_of(n + 1, st + 1 == nblk ? 0 : st + 1, lane);
+      if (!FULL) delta_of(n + 1, st + 1 == nblk ? 0 : st + 1, lane);
       ATT_STAMP(4 + 6 * st);
       // behind a wave's pieces of block n+2 (requested in step n-1) are at least its pieces of block n+3: two (waves 0-5),
       // one (wave 6: lse); wave 7 has no ring piece
@@ -1474,6 +1490,7 @@ static int attn_check(const char* who, int B, int S, int nh, float p) {
 
 using namespace czc;
 
+static int g_attn_stream_full = -1;   // CZC_ATTN_STREAM_FULL=0: the general streaming kernel at 256 tokens too (A/B runs)
 static int g_attn_stream_bwd = -1;  // CZC_ATTN_STREAM_BWD=0: the one-workgroup-per-item fused backward instead of the streaming one (A/B runs)
 static int g_attn_fused_bwd = -1;   // CZC_ATTN_FUSED_BWD=0 keeps the two-kernel backward for short sequences too (A/B runs)
 
@@ -1532,8 +1549,14 @@ extern "C" int czc_attention_backward(const uint16_t* qkv, const uint8_t* mask, 
     }
     const int items = batch * heads;
     dim3 gridp(items < cus ? items : cus);
-    if (a.thr) hipLaunchKernelGGL(attn_bwd_stream_kernel<true>, gridp, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL(attn_bwd_stream_kernel<false>, gridp, dim3(512), 0, st, a);
+    if (g_attn_stream_full < 0) { const char* e = getenv("CZC_ATTN_STREAM_FULL"); g_attn_stream_full = (e && e[0] == '0') ? 0 : 1; }
+    if (seq == 256 && g_attn_stream_full) {
+      if (a.thr) hipLaunchKernelGGL((attn_bwd_stream_kernel<true, true>), gridp, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((attn_bwd_stream_kernel<false, true>), gridp, dim3(512), 0, st, a);
+    } else {
+      if (a.thr) hipLaunchKernelGGL((attn_bwd_stream_kernel<true, false>), gridp, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((attn_bwd_stream_kernel<false, false>), gridp, dim3(512), 0, st, a);
+    }
     CZC_LAUNCH_CHECK();
     if (d_bias_qkv) return czc_reduce_partials(partials, batch, 3 * a.H, 3 * a.H, d_bias_qkv, stream);
     return CZC_OK;
