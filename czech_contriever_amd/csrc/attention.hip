@@ -1056,7 +1056,9 @@ __device__ __forceinline__ bf16x8 frag_img16(const unsigned char* img, int row0,
 // count is a constant -- the wave-uniform branches that guard those cases split the step into many basic blocks, and the
 // compiler schedules inside a block only; without them the dQ chain and the delta chain sit in ONE block with the softmax
 // arithmetic and their LDS / MFMA latencies run under it.
-template <bool DROP, bool FULL>
+// PIPE (with FULL): the S / dP products of block n+1 are issued at the top of step n, before the softmax arithmetic of block n
+// (whose scores were made a step earlier): their fragment reads and MFMA latency run under it.
+template <bool DROP, bool FULL, bool PIPE>
 __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs a) {
   constexpr int ST = 12544, O_LSE = 50176, O_DEL = 50688, O_DS = 51200, O_OUT = 83968, O_K = 92160, O_V = 124928, O_RED = 157696;
   __shared__ __attribute__((aligned(16))) unsigned char smem[159744];
@@ -1209,6 +1211,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
       if (FULL || i < nblk) kT[i] = frag_img16(kimg, 32 * i, 16 * dc, lane);
     kbias = ((k0 + (lane & 31)) < S && kmask) ? 0.f : NEG_MASK;
   };
+  auto sdp_of = [&](int m, f32x16& so, f32x16& dpo, int lane) {   // S = Q K^T and dP = dO V^T of block m (stage m & 3), this wave's 32 keys
+    const unsigned char* sg = smem + (m & 3) * ST;
+    so = dpo = (f32x16)(0.f);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      so = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sg, 0, ks, lane), bk[ks], so, 0, 0, 0);
+      dpo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sg + 4096, 0, ks, lane), bv[ks], dpo, 0, 0, 0);
+    }
+  };
+  f32x16 s_cur = (f32x16)(0.f), dp_cur = (f32x16)(0.f);   // PIPE: the scores of the block the next step works on
   f32x16 dk[2], dv[2];
   f32x4 dqsum = (f32x4)(0.f);
   dk[0] = dk[1] = dv[0] = dv[1] = (f32x16)(0.f);
@@ -1249,6 +1261,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
     ATT_BAR();
     delta_of(0, 0, lane);
     take_fragments(kmask, lane);
+    if (PIPE) sdp_of(0, s_cur, dp_cur, lane);
     ATT_BAR();
   }
 
@@ -1297,11 +1310,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
       }
       ATT_STAMP(2 + 6 * st);
       if (active) {
-        f32x16 s = (f32x16)(0.f), dp = (f32x16)(0.f);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(qt, 0, ks, lane), bk[ks], s, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(dot, 0, ks, lane), bv[ks], dp, 0, 0, 0);
+        f32x16 s, dp;
+        if (PIPE) {   // this block's scores were made a step ago; the next block's are requested now (at an item's last step
+                      // they are made with the wrong K / V and never used: the seam makes the next item's first ones)
+          s = s_cur; dp = dp_cur;
+          sdp_of(n + 1, s_cur, dp_cur, lane);
+        } else {
+          sdp_of(n, s, dp, lane);
         }
         if (FULL) {   // the two short chains in the same basic block as the softmax arithmetic
           dq_block(n - 1, lane, st > 0);
@@ -1413,7 +1428,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
         pv[4 * dt + g] = make_uint2(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]));
       }
     dk[0] = dk[1] = dv[0] = dv[1] = (f32x16)(0.f);
-    if (has_next) take_fragments((uint8_t)(kmask_n & 0xffu), lane);
+    if (has_next) {
+      take_fragments((uint8_t)(kmask_n & 0xffu), lane);
+      if (PIPE) sdp_of(n, s_cur, dp_cur, lane);
+    }
     ATT_BAR();
     ATT_STAMP(62);
     // bf16 [256 keys][64] images in the staging area (a lane owns a row; keys past S are zeros)
@@ -1490,7 +1508,7 @@ static int attn_check(const char* who, int B, int S, int nh, float p) {
 
 using namespace czc;
 
-static int g_attn_stream_full = -1;   // CZC_ATTN_STREAM_FULL=0: the general streaming kernel at 256 tokens too (A/B runs)
+static int g_attn_stream_full = -1;   // CZC_ATTN_STREAM_FULL=0: the general streaming kernel at 256 tokens too, 1: specialised without the S / dP pipeline, 2 (default): with it (A/B runs)
 static int g_attn_stream_bwd = -1;  // CZC_ATTN_STREAM_BWD=0: the one-workgroup-per-item fused backward instead of the streaming one (A/B runs)
 static int g_attn_fused_bwd = -1;   // CZC_ATTN_FUSED_BWD=0 keeps the two-kernel backward for short sequences too (A/B runs)
 
@@ -1549,13 +1567,16 @@ extern "C" int czc_attention_backward(const uint16_t* qkv, const uint8_t* mask, 
     }
     const int items = batch * heads;
     dim3 gridp(items < cus ? items : cus);
-    if (g_attn_stream_full < 0) { const char* e = getenv("CZC_ATTN_STREAM_FULL"); g_attn_stream_full = (e && e[0] == '0') ? 0 : 1; }
-    if (seq == 256 && g_attn_stream_full) {
-      if (a.thr) hipLaunchKernelGGL((attn_bwd_stream_kernel<true, true>), gridp, dim3(512), 0, st, a);
-      else hipLaunchKernelGGL((attn_bwd_stream_kernel<false, true>), gridp, dim3(512), 0, st, a);
+    if (g_attn_stream_full < 0) { const char* e = getenv("CZC_ATTN_STREAM_FULL"); g_attn_stream_full = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }
+    if (seq == 256 && g_attn_stream_full == 2) {
+      if (a.thr) hipLaunchKernelGGL((attn_bwd_stream_kernel<true, true, true>), gridp, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((attn_bwd_stream_kernel<false, true, true>), gridp, dim3(512), 0, st, a);
+    } else if (seq == 256 && g_attn_stream_full) {
+      if (a.thr) hipLaunchKernelGGL((attn_bwd_stream_kernel<true, true, false>), gridp, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((attn_bwd_stream_kernel<false, true, false>), gridp, dim3(512), 0, st, a);
     } else {
-      if (a.thr) hipLaunchKernelGGL((attn_bwd_stream_kernel<true, false>), gridp, dim3(512), 0, st, a);
-      else hipLaunchKernelGGL((attn_bwd_stream_kernel<false, false>), gridp, dim3(512), 0, st, a);
+      if (a.thr) hipLaunchKernelGGL((attn_bwd_stream_kernel<true, false, false>), gridp, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((attn_bwd_stream_kernel<false, false, false>), gridp, dim3(512), 0, st, a);
     }
     CZC_LAUNCH_CHECK();
     if (d_bias_qkv) return czc_reduce_partials(partials, batch, 3 * a.H, 3 * a.H, d_bias_qkv, stream);
