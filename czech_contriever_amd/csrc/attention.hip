@@ -319,6 +319,12 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_res_kernel(const AttnArgs a) 
 
   f32x16 o[2];
   o[0] = o[1] = (f32x16)(0.f);
+  // Online softmax with a LAZY reference point: m follows the running maximum only when that exceeds it by more than
+  // 2^DEFER (log2 units), so most tiles skip the rescaling of O and l (alpha == 1 in every lane: the __any below).
+  // Probabilities reach at most 2^DEFER instead of 1: exact in fp32 / bf16 terms (same mantissa, larger exponent), and
+  // O / l and lse = m + log2 l do not depend on the reference point.  (Requesting the next tile's scores before this
+  // tile's softmax arithmetic was measured too: 113 us against 108, four waves per SIMD hide that latency already.)
+  constexpr float DEFER = 8.0f;
   float m = -1.0e30f, l = 0.f;
   const uint32_t S4 = (uint32_t)((S + 3) & ~3);
   const uint32_t rkey = czc_rng_key(a.seed, a.site);
@@ -343,6 +349,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_res_kernel(const AttnArgs a) 
         }
       }
       mx = xor32_max(mx);
+      mx = (mx > m + DEFER) ? mx : m;          // the reference point moves only when the maximum outgrew it by 2^DEFER
       alpha = __builtin_amdgcn_exp2f(m - mx);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -357,6 +364,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_res_kernel(const AttnArgs a) 
       rm = fmaxf(rm, s[15]);
       mx = fmaxf(m, rm * c2);
       mx = xor32_max(mx);
+      mx = (mx > m + DEFER) ? mx : m;
       alpha = __builtin_amdgcn_exp2f(m - mx);
       const float nmx = -mx;
 #pragma unroll
