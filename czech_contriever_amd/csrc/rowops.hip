@@ -82,11 +82,14 @@ __device__ __forceinline__ LnStat row_stats(const f32x4* v, int H, int lane, flo
 // ---------------------------------------------------------------------------------------------
 // x = LN(dropout(y) + resid)
 // ---------------------------------------------------------------------------------------------
-template <int NIT>
+// EXACT: the row is exactly NIT * 256 elements (768, 1024 ...): every "column < H" guard is true at compile time, the
+// row's loads, arithmetic and stores form one basic block
+template <int NIT, bool EXACT>
 __global__ __launch_bounds__(256) void residual_ln_fwd_kernel(
-    const bf16_t* __restrict__ y, const bf16_t* __restrict__ resid, int rows, int H,
+    const bf16_t* __restrict__ y, const bf16_t* __restrict__ resid, int rows, int H_,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     uint32_t thr, float inv_keep, uint32_t seed, uint32_t site, bf16_t* __restrict__ x, float* __restrict__ stats) {
+  const int H = EXACT ? NIT * 256 : H_;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   f32x4 gm[NIT], bt[NIT];
 #pragma unroll
@@ -194,12 +197,13 @@ static void launch_reduce_partials(const float* part, int nrows, int row_stride,
                      ncols, dst);
 }
 
-template <int NIT>
+template <int NIT, bool EXACT>
 __global__ __launch_bounds__(256, NIT <= 3 ? 4 : 2) void residual_ln_bwd_kernel(
     const bf16_t* __restrict__ dx, const bf16_t* __restrict__ dx2, const bf16_t* __restrict__ y,
-    const bf16_t* __restrict__ resid, const float* __restrict__ stats, int rows, int H,
+    const bf16_t* __restrict__ resid, const float* __restrict__ stats, int rows, int H_,
     const float* __restrict__ gamma, uint32_t thr, float inv_keep, uint32_t seed, uint32_t site,
     bf16_t* __restrict__ dz_out, bf16_t* __restrict__ dy_out, float* d_gamma, float* d_beta, float* d_bias, float* part) {
+  const int H = EXACT ? NIT * 256 : H_;
   __shared__ float lds_acc[3 * 1024];
   for (int i = threadIdx.x; i < 3 * 1024; i += blockDim.x) lds_acc[i] = 0.f;
   __syncthreads();
@@ -520,6 +524,16 @@ using namespace czc;
     else hipLaunchKernelGGL(kern<4>, grid, dim3(256), 0, st, __VA_ARGS__);                         \
   } while (0)
 
+#define LAUNCH_NIT_EXACT(kern, H, grid, st, ...)                                                   \
+  do {                                                                                              \
+    if ((H) == 768) hipLaunchKernelGGL((kern<3, true>), grid, dim3(256), 0, st, __VA_ARGS__);       \
+    else if ((H) == 1024) hipLaunchKernelGGL((kern<4, true>), grid, dim3(256), 0, st, __VA_ARGS__); \
+    else if ((H) <= 256) hipLaunchKernelGGL((kern<1, false>), grid, dim3(256), 0, st, __VA_ARGS__); \
+    else if ((H) <= 512) hipLaunchKernelGGL((kern<2, false>), grid, dim3(256), 0, st, __VA_ARGS__); \
+    else if ((H) <= 768) hipLaunchKernelGGL((kern<3, false>), grid, dim3(256), 0, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((kern<4, false>), grid, dim3(256), 0, st, __VA_ARGS__);                 \
+  } while (0)
+
 #define DROP_ARGS(p) \
   const uint32_t thr = (p) > 0.f ? czc_drop_thr(p) : 0u; \
   const float inv_keep = (p) > 0.f ? 1.0f / (1.0f - (p)) : 1.0f
@@ -531,7 +545,7 @@ extern "C" int czc_residual_ln_forward(const uint16_t* y, const uint16_t* resid,
   CZC_REQUIRE(rows > 0 && dropout_p >= 0.f && dropout_p < 1.f, "czc_residual_ln_forward: rows=%d p=%f", rows, dropout_p);
   ProfScope prof((hipStream_t)stream, "residual_ln_fwd", 0.0, 2.0 * rows * (double)hidden * 3.0 + 8.0 * rows);
   DROP_ARGS(dropout_p);
-  LAUNCH_NIT(residual_ln_fwd_kernel, hidden, dim3(row_grid(rows)), (hipStream_t)stream, y, resid, rows, hidden, gamma, beta,
+  LAUNCH_NIT_EXACT(residual_ln_fwd_kernel, hidden, dim3(row_grid(rows)), (hipStream_t)stream, y, resid, rows, hidden, gamma, beta,
              eps, thr, inv_keep, seed, site, x, stats);
   CZC_LAUNCH_CHECK();
   return CZC_OK;
@@ -553,7 +567,7 @@ extern "C" int czc_residual_ln_backward(const uint16_t* dx, const uint16_t* dx2,
   // 512 -> 200 us at 65536 x 768)
   int g = row_grid(rows);
   if (g > 1024) g = 1024;
-  LAUNCH_NIT(residual_ln_bwd_kernel, hidden, dim3(g), (hipStream_t)stream, dx, dx2, y, resid, stats, rows, hidden, gamma, thr,
+  LAUNCH_NIT_EXACT(residual_ln_bwd_kernel, hidden, dim3(g), (hipStream_t)stream, dx, dx2, y, resid, stats, rows, hidden, gamma, thr,
              inv_keep, seed, site, dz_out, dy_out, d_gamma, d_beta, d_bias, partials);
   if (partials) launch_reduce_partials3(partials, g, hidden, d_gamma, d_beta, d_bias, (hipStream_t)stream);
   CZC_LAUNCH_CHECK();
