@@ -93,14 +93,35 @@ __global__ __launch_bounds__(256) void colstd_kernel(const float* __restrict__ x
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
+  // sixteen rows' loads in flight per thread (a rolled loop pays one memory round trip per row: 28 us for 0.8 MB)
   float m = 0.f;
-  if (c < C) for (int b = w; b < B; b += 4) m += x[(size_t)b * C + c];
+  if (c < C) {
+    int b = w;
+    for (; b + 60 < B; b += 64) {
+      float t[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t[i] = x[(size_t)(b + 4 * i) * C + c];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) m += t[i];
+    }
+    for (; b < B; b += 4) m += x[(size_t)b * C + c];
+  }
   red[w][lane] = m;
   __syncthreads();
   m = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)B;
   __syncthreads();
   float v = 0.f;
-  if (c < C) for (int b = w; b < B; b += 4) { const float d = x[(size_t)b * C + c] - m; v += d * d; }
+  if (c < C) {
+    int b = w;
+    for (; b + 60 < B; b += 64) {
+      float t[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t[i] = x[(size_t)(b + 4 * i) * C + c];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const float d = t[i] - m; v += d * d; }
+    }
+    for (; b < B; b += 4) { const float d = x[(size_t)b * C + c] - m; v += d * d; }
+  }
   red[w][lane] = v;
   __syncthreads();
   if (w == 0) {
