@@ -25,3 +25,4 @@ print(f"residual_ln fwd p=0.1        {timeit(lambda: ops.residual_ln_forward(X, 
 print(f"residual_ln fwd p=0          {timeit(lambda: ops.residual_ln_forward(X, Y, gam, bet, 1e-12, 0.0, 5, 7)):7.1f} us")
 print(f"residual_ln bwd p=0.1        {timeit(lambda: ops.residual_ln_backward(D, None, X, Y, st, gam, dg, dbb, dbi, 0.1, 5, 7)):7.1f} us (+ reduce)")
 print(f"residual_ln bwd p=0.1 + dx2  {timeit(lambda: ops.residual_ln_backward(D, D2, X, Y, st, gam, dg, dbb, dbi, 0.1, 5, 7)):7.1f} us (+ reduce)")
+print(f"residual_ln bwd p=0          {timeit(lambda: ops.residual_ln_backward(D, None, X, Y, st, gam, dg, dbb, dbi, 0.0, 5, 7)):7.1f} us (+ reduce)")
