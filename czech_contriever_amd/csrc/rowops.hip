@@ -361,10 +361,21 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(
     const int c = (lane + 64 * it) * 4;
     gm[it] = (c < H) ? *(const f32x4*)(gamma + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+  // A wave walks over units of work = one position s x a chunk of the batch (rows b*S + s for b in the chunk): the
+  // position-embedding gradient of the chunk stays in registers and is added to d_pos ONCE per unit.  Float atomics run
+  // at one 256-byte instruction per ~120 cycles per CU whatever the address pattern: a row of atomics per token into
+  // d_pos doubled the kernel's atomic traffic for a tensor that has 256 rows.
+  const int Bt = rows / S;
+  const int CH = Bt >= 256 ? 16 : (Bt >= 16 ? Bt / 16 : 1), per = (Bt + CH - 1) / CH;
+  for (int u = blockIdx.x * 4 + wave; u < S * CH; u += gridDim.x * 4) {
+   const int s = u / CH, b0 = (u - s * CH) * per, b1 = min(Bt, b0 + per);
+   f32x4 pacc[NIT];
+#pragma unroll
+   for (int it = 0; it < NIT; ++it) pacc[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+   for (int b = b0; b < b1; ++b) {
+    const int row = b * S + s;
     int64_t id = ids[row];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-    const int s = row % S;
     const size_t base = (size_t)row * H;
     const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
     f32x4 xh[NIT], gh[NIT];
@@ -394,16 +405,22 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(
       if (c < H) {
         const f32x4 dz = (gh[it] - s1 - xh[it] * s2) * rstd;
         acc[2][it] += dz;
+        pacc[it] += dz;
         *(f32x4*)(tr + c) = dz;     // wave-private row image in LDS
       }
     }
     // scatter-add with every atomic wave-instruction covering 256 CONTIGUOUS bytes (lane l -> element 64k + l):
     // four 4-byte adds 16 B apart per lane ran at a quarter of this rate (MI355X float-atomic access shape)
-    for (int c = lane; c < H; c += 64) {
-      const float v = tr[c];
-      unsafeAtomicAdd(d_word + (size_t)id * H + c, v);
-      unsafeAtomicAdd(d_pos + (size_t)s * H + c, v);
+    for (int c = lane; c < H; c += 64) unsafeAtomicAdd(d_word + (size_t)id * H + c, tr[c]);
+   }
+   if (b1 > b0) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = (lane + 64 * it) * 4;
+      if (c < H) *(f32x4*)(tr + c) = pacc[it];
     }
+    for (int c = lane; c < H; c += 64) unsafeAtomicAdd(d_pos + (size_t)s * H + c, tr[c]);
+   }
   }
   flush_colsums<NIT>(lds_acc, acc, H, lane, d_gamma, d_beta, d_type0, part);
 }
