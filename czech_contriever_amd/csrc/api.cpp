@@ -25,6 +25,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
 
 // ---- per-operation timing ----
 bool g_prof_on = false;
+int g_defer_partials = 0;
 namespace {
 struct ProfEntry {
   std::string name;

@@ -1520,6 +1520,14 @@ static int g_attn_stream_full = -1;   // CZC_ATTN_STREAM_FULL=0: the general str
 static int g_attn_stream_bwd = -1;  // CZC_ATTN_STREAM_BWD=0: the one-workgroup-per-item fused backward instead of the streaming one (A/B runs)
 static int g_attn_fused_bwd = -1;   // CZC_ATTN_FUSED_BWD=0 keeps the two-kernel backward for short sequences too (A/B runs)
 
+namespace czc {
+// one partial row per batch row from the single-pass kernels, one per (batch row, 128-query block) from the kernel pair
+int attn_bwd_partial_rows(int batch, int seq) {
+  if (g_attn_fused_bwd < 0) { const char* e = getenv("CZC_ATTN_FUSED_BWD"); g_attn_fused_bwd = (e && e[0] == '0') ? 0 : 1; }
+  return (seq <= 256 && g_attn_fused_bwd) ? batch : batch * ceil_div(seq, 128);
+}
+}  // namespace czc
+
 extern "C" int64_t czc_attention_bias_scratch_floats(int batch, int seq, int heads) {
   return (int64_t)batch * ceil_div(seq, 128) * 3 * heads * 64;
 }
@@ -1587,7 +1595,7 @@ extern "C" int czc_attention_backward(const uint16_t* qkv, const uint8_t* mask, 
       else hipLaunchKernelGGL((attn_bwd_stream_kernel<false, false, false>), gridp, dim3(512), 0, st, a);
     }
     CZC_LAUNCH_CHECK();
-    if (d_bias_qkv) return czc_reduce_partials(partials, batch, 3 * a.H, 3 * a.H, d_bias_qkv, stream);
+    if (d_bias_qkv && !g_defer_partials) return czc_reduce_partials(partials, batch, 3 * a.H, 3 * a.H, d_bias_qkv, stream);
     return CZC_OK;
   }
   if (seq <= 256 && g_attn_fused_bwd) {   // one pass over the scores for dQ, dK and dV
@@ -1596,7 +1604,7 @@ extern "C" int czc_attention_backward(const uint16_t* qkv, const uint8_t* mask, 
     if (a.thr) hipLaunchKernelGGL(attn_bwd_fused_kernel<true>, grid1, dim3(512), 0, st, a);
     else hipLaunchKernelGGL(attn_bwd_fused_kernel<false>, grid1, dim3(512), 0, st, a);
     CZC_LAUNCH_CHECK();
-    if (d_bias_qkv) return czc_reduce_partials(partials, batch, 3 * a.H, 3 * a.H, d_bias_qkv, stream);
+    if (d_bias_qkv && !g_defer_partials) return czc_reduce_partials(partials, batch, 3 * a.H, 3 * a.H, d_bias_qkv, stream);
     return CZC_OK;
   }
   dim3 grid(ceil_div(seq, 128), heads, batch);
@@ -1608,6 +1616,6 @@ extern "C" int czc_attention_backward(const uint16_t* qkv, const uint8_t* mask, 
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, grid, dim3(256), 0, st, a);
   }
   CZC_LAUNCH_CHECK();
-  if (d_bias_qkv) return czc_reduce_partials(partials, batch * (int)grid.x, 3 * a.H, 3 * a.H, d_bias_qkv, stream);
+  if (d_bias_qkv && !g_defer_partials) return czc_reduce_partials(partials, batch * (int)grid.x, 3 * a.H, 3 * a.H, d_bias_qkv, stream);
   return CZC_OK;
 }

@@ -43,6 +43,20 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 extern bool g_prof_on;
 int prof_begin(hipStream_t st, const char* name, double flops, double bytes);
 void prof_end(hipStream_t st, int handle);
+// One batched reduction of several kernels' per-workgroup partial rows (the encoder's backward: the two LayerNorms, the
+// dGELU bias and the attention QKV bias of a layer leave four sets of partial rows; four separate reduce launches of 5 us
+// each were latency, not work).  While g_defer_partials is set the row kernels and the attention backward skip their own
+// reduction; the caller describes the jobs and calls multi_reduce.
+struct ReduceJob {
+  const float* src;   // [nrows][row_stride] partial rows
+  int nrows, row_stride, ncols, seg;   // column c is added to dst[c / seg][c % seg]
+  float* dst[3];      // null entries are skipped
+};
+extern int g_defer_partials;
+int multi_reduce(const ReduceJob* jobs, int njobs, hipStream_t st);   // rowops.hip
+int ln_bwd_partial_rows(int rows);                                     // rows of partials czc_residual_ln_backward writes
+int attn_bwd_partial_rows(int batch, int seq);                         // rows of partials czc_attention_backward writes (after a call)
+
 struct ProfScope {
   hipStream_t st;
   int h;

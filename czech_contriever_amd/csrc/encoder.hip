@@ -103,7 +103,7 @@ static EncLayout enc_layout(const czc_bert_shape* s, int B, int S, int save) {
   return e;
 }
 
-struct BwdLayout { int64_t g0, z, y, x1, c, q3, u, delta, part, slabs, total; int64_t slab_bytes; };
+struct BwdLayout { int64_t g0, z, y, x1, c, q3, u, delta, part, part_ln1, part_gelu, part_attn, slabs, total; int64_t slab_bytes; };
 static int dw_splits(int Mo, int No, int64_t Kred) {
   const int tiles = ceil_div(Mo, 256) * ceil_div(No, 256);
   int sp = 256 / tiles;
@@ -128,6 +128,10 @@ static BwdLayout bwd_layout(const czc_bert_shape* s, int B, int S) {
     if (af > pf) pf = af;
     if (gf > pf) pf = gf;
     b.part = take(pf * 4);
+    // a layer's four sets of partial rows live side by side: they are reduced by ONE launch at the end of the layer
+    b.part_ln1 = take(czc_colsum_scratch_floats((int)H) * 4);
+    b.part_gelu = take(gf * 4);
+    b.part_attn = take(af * 4);
   }
   int64_t sb = 0;
   auto need = [&](int Mo, int No) { int64_t v = (int64_t)dw_splits(Mo, No, M) * Mo * No * 4; if (v > sb) sb = v; };
@@ -348,7 +352,11 @@ extern "C" int czc_encoder_backward(const czc_bert_shape* s, const float* params
   uint16_t* X1 = SBUF(bl.x1); uint16_t* C = SBUF(bl.c); uint16_t* Q3 = SBUF(bl.q3); uint16_t* U = SBUF(bl.u);
   float* delta = (float*)(sc + bl.delta);
   float* part = (float*)(sc + bl.part);
+  float* part_ln1 = (float*)(sc + bl.part_ln1);
+  float* part_gelu = (float*)(sc + bl.part_gelu);
+  float* part_attn = (float*)(sc + bl.part_attn);
   float* slabs = (float*)(sc + bl.slabs);
+  struct DeferGuard { DeferGuard() { g_defer_partials = 1; } ~DeferGuard() { g_defer_partials = 0; } };
 
   auto dweight = [&](int Mo, int No, const uint16_t* dY, int ldy, const uint16_t* X, int ldx, float* dst) -> int {
     const int sp = dw_splits(Mo, No, M);
@@ -360,21 +368,33 @@ extern "C" int czc_encoder_backward(const czc_bert_shape* s, const float* params
   if (first) RC(czc_pool_backward(d_emb, FBUF(e.raw), mask, batch, seq, H, pooling, normalize, g0, stream));
   for (int l = layer_hi - 1; l >= layer_lo; --l) {
     const LayerWs& w = e.layer[l];
-    // x[l+1] = LN(drop(y2) + x1)
-    RC(czc_residual_ln_backward(g0, nullptr, BUF(w.y2), BUF(w.x1), FBUF(w.st2), M, H, PF(CZC_P_LN2W, l), ph, seed,
-                                SITE_H2(l), Z, Y, GF(CZC_P_LN2W, l), GF(CZC_P_LN2B, l), GF(CZC_P_B2, l), part, stream));
-    RC(dweight(H, I, Y, H, BUF(w.hact), I, GF(CZC_P_W2, l)));
-    RC(dinput(EPI_DGELU, M, I, H, Y, H, CZC_P_W2, l, U, I, BUF(w.u), part));
-    RC(czc_reduce_partials(part, ceil_div(M, 256) * 2, I, I, GF(CZC_P_B1, l), stream));
-    RC(dweight(I, H, U, I, BUF(w.x1), H, GF(CZC_P_W1, l)));
-    RC(dinput(EPI_ADD, M, H, I, U, I, CZC_P_W1, l, X1, H, Z, nullptr));
-    // x1 = LN(drop(y1) + x[l])
-    RC(czc_residual_ln_backward(X1, nullptr, BUF(w.y1), BUF(e.x[l]), FBUF(w.st1), M, H, PF(CZC_P_LN1W, l), ph, seed,
-                                SITE_H1(l), Z, Y, GF(CZC_P_LN1W, l), GF(CZC_P_LN1B, l), GF(CZC_P_BO, l), part, stream));
-    RC(dweight(H, H, Y, H, BUF(w.ctx), H, GF(CZC_P_WO, l)));
-    RC(dinput(EPI_STORE, M, H, H, Y, H, CZC_P_WO, l, C, H, nullptr, nullptr));
-    RC(czc_attention_backward(BUF(w.qkv), mask, BUF(w.ctx), C, FBUF(w.lse), batch, seq, nh, pa, seed, SITE_ATTN(l), delta, Q3,
-                              GF(CZC_P_BQKV, l), part, stream));
+    {
+      DeferGuard defer;   // the four kernels below leave their partial rows; one reduction at the end of the layer
+      // x[l+1] = LN(drop(y2) + x1)
+      RC(czc_residual_ln_backward(g0, nullptr, BUF(w.y2), BUF(w.x1), FBUF(w.st2), M, H, PF(CZC_P_LN2W, l), ph, seed,
+                                  SITE_H2(l), Z, Y, GF(CZC_P_LN2W, l), GF(CZC_P_LN2B, l), GF(CZC_P_B2, l), part, stream));
+      RC(dweight(H, I, Y, H, BUF(w.hact), I, GF(CZC_P_W2, l)));
+      RC(dinput(EPI_DGELU, M, I, H, Y, H, CZC_P_W2, l, U, I, BUF(w.u), part_gelu));
+      RC(dweight(I, H, U, I, BUF(w.x1), H, GF(CZC_P_W1, l)));
+      RC(dinput(EPI_ADD, M, H, I, U, I, CZC_P_W1, l, X1, H, Z, nullptr));
+      // x1 = LN(drop(y1) + x[l])
+      RC(czc_residual_ln_backward(X1, nullptr, BUF(w.y1), BUF(e.x[l]), FBUF(w.st1), M, H, PF(CZC_P_LN1W, l), ph, seed,
+                                  SITE_H1(l), Z, Y, GF(CZC_P_LN1W, l), GF(CZC_P_LN1B, l), GF(CZC_P_BO, l), part_ln1, stream));
+      RC(dweight(H, H, Y, H, BUF(w.ctx), H, GF(CZC_P_WO, l)));
+      RC(dinput(EPI_STORE, M, H, H, Y, H, CZC_P_WO, l, C, H, nullptr, nullptr));
+      RC(czc_attention_backward(BUF(w.qkv), mask, BUF(w.ctx), C, FBUF(w.lse), batch, seq, nh, pa, seed, SITE_ATTN(l), delta, Q3,
+                                GF(CZC_P_BQKV, l), part_attn, stream));
+    }
+    {
+      const int lnr = ln_bwd_partial_rows(M);
+      const int ar = attn_bwd_partial_rows(batch, seq);
+      ReduceJob jobs[4] = {
+          {part, lnr, 3 * H, 3 * H, H, {GF(CZC_P_LN2W, l), GF(CZC_P_LN2B, l), GF(CZC_P_B2, l)}},
+          {part_gelu, ceil_div(M, 256) * 2, I, I, I, {GF(CZC_P_B1, l), nullptr, nullptr}},
+          {part_ln1, lnr, 3 * H, 3 * H, H, {GF(CZC_P_LN1W, l), GF(CZC_P_LN1B, l), GF(CZC_P_BO, l)}},
+          {part_attn, ar, 3 * H, 3 * H, 3 * H, {GF(CZC_P_BQKV, l), nullptr, nullptr}}};
+      RC(multi_reduce(jobs, 4, st));
+    }
     RC(dweight(3 * H, H, Q3, 3 * H, BUF(e.x[l]), H, GF(CZC_P_WQKV, l)));
     RC(dinput(EPI_ADD, M, H, 3 * H, Q3, 3 * H, CZC_P_WQKV, l, g0, H, Z, nullptr));
   }

@@ -204,6 +204,62 @@ __global__ __launch_bounds__(256) void reduce_partials3_kernel(const float* __re
     if (d) unsafeAtomicAdd(d + cc, s);
   }
 }
+struct MultiReduceArgs { ReduceJob j[4]; int first[5]; int chunks[4]; };
+// block -> (job, 64-column block, row chunk); 64 columns x 4 row lanes per block, eight rows' loads in flight per thread
+__global__ __launch_bounds__(256) void multi_reduce_kernel(const MultiReduceArgs a) {
+  __shared__ float red[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  int k = 0;
+  while (k < 3 && (int)blockIdx.x >= a.first[k + 1]) ++k;
+  const ReduceJob& jb = a.j[k];
+  const int local = blockIdx.x - a.first[k], chunks = a.chunks[k];
+  const int c = (local / chunks) * 64 + cx, chunk = local % chunks;
+  float s = 0.f;
+  if (c < jb.ncols) {
+    const float* src = jb.src + c;
+    int r = chunk * 4 + ry;
+    const int step = chunks * 4;
+    for (; r + 7 * step < jb.nrows; r += 8 * step) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = src[(size_t)(r + i * step) * jb.row_stride];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += v[i];
+    }
+    for (; r < jb.nrows; r += step) s += src[(size_t)r * jb.row_stride];
+  }
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && c < jb.ncols) {
+    s = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+    const int sg = c / jb.seg, cc = c - sg * jb.seg;
+    float* d = jb.dst[sg];
+    if (d) unsafeAtomicAdd(d + cc, s);
+  }
+}
+int multi_reduce(const ReduceJob* jobs, int njobs, hipStream_t st) {
+  CZC_REQUIRE(njobs >= 1 && njobs <= 4, "multi_reduce: %d jobs", njobs);
+  MultiReduceArgs a{};
+  int nb = 0;
+  for (int k = 0; k < 4; ++k) {
+    a.first[k] = nb;
+    if (k < njobs) {
+      a.j[k] = jobs[k];
+      int ch = jobs[k].nrows / 32;
+      ch = ch < 1 ? 1 : (ch > 16 ? 16 : ch);
+      a.chunks[k] = ch;
+      nb += ceil_div(jobs[k].ncols, 64) * ch;
+    } else {
+      a.chunks[k] = 1;
+    }
+  }
+  a.first[4] = nb;
+  for (int k = njobs; k < 4; ++k) a.first[k] = nb;
+  hipLaunchKernelGGL(multi_reduce_kernel, dim3(nb), dim3(256), 0, st, a);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
 static void launch_reduce_partials3(const float* part, int nrows, int H, float* d0, float* d1, float* d2, hipStream_t st) {
   int chunks = nrows / 32;
   if (chunks < 1) chunks = 1;
@@ -553,6 +609,7 @@ static int row_grid(int rows) {
   return g > 2048 ? 2048 : (g < 1 ? 1 : g);
 }
 static bool hidden_ok(int H) { return H > 0 && H <= 1024 && (H % 8) == 0; }
+int ln_bwd_partial_rows(int rows) { const int g = row_grid(rows); return g > 1024 ? 1024 : g; }
 
 }  // namespace czc
 
@@ -611,7 +668,7 @@ extern "C" int czc_residual_ln_backward(const uint16_t* dx, const uint16_t* dx2,
   if (g > 1024) g = 1024;
   LAUNCH_NIT_EXACT(residual_ln_bwd_kernel, hidden, dim3(g), (hipStream_t)stream, dx, dx2, y, resid, stats, rows, hidden, gamma, thr,
              inv_keep, seed, site, dz_out, dy_out, d_gamma, d_beta, d_bias, partials);
-  if (partials) launch_reduce_partials3(partials, g, hidden, d_gamma, d_beta, d_bias, (hipStream_t)stream);
+  if (partials && !g_defer_partials) launch_reduce_partials3(partials, g, hidden, d_gamma, d_beta, d_bias, (hipStream_t)stream);
   CZC_LAUNCH_CHECK();
   return CZC_OK;
 }
