@@ -99,6 +99,10 @@ struct AttnArgs {
   const bf16_t* qkv; const uint8_t* mask; const bf16_t* ctx; const bf16_t* dctx;
   const float* lse_in; float* lse; float* delta; bf16_t* out; bf16_t* dqkv;
   float* dbias;  // per-workgroup partial column sums of dqkv: [gridDim.z * gridDim.x][3H] (null = not wanted)
+  // dropout keep bits of the probabilities, seq <= 256 (null = not kept): word [(b * heads + head) * 8 + q / 32][pos(key)],
+  // pos(k) = 32 (k / 32) + 8 ((k % 32) / 8) + 2 (k % 4) + (k / 4) % 2, has bit (q % 32) set iff probability (q, key) is kept.  The resident forward writes them from the compare masks it
+  // forms anyway, the streaming backward reads one word per lane and step instead of hashing again.
+  uint32_t* bits;
   int B, S, nh, H;
   uint32_t thr, seed, site;
   float inv_keep;
@@ -262,7 +266,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
 // 32-key tiles independently -- no per-block barrier, no double buffer, K/V read from HBM once instead of once per
 // 128 queries, and 128 VGPRs = four waves per SIMD (two workgroups per CU).  The loop body is the streaming kernel's.
 // ---------------------------------------------------------------------------------------------
-template <bool DROP>
+// KEEP (with DROP): the keep words are exported (AttnArgs::bits); a template parameter, not a test of the pointer: the
+// pointer test inside the dropout block cost the plain forward 12 % (119 us against 107)
+template <bool DROP, bool KEEP>
 __global__ __launch_bounds__(512, 4) void attn_fwd_res_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char kt[256 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char vt[256 * 128];
@@ -381,13 +387,30 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_res_kernel(const AttnArgs a) 
       o[1] *= alpha;
     }
     if (DROP) {   // drop = select 0; the 1/(1-p) scale is applied once, to the final O
+      // keep words (AttnArgs::bits): the compare mask of register (g, j) IS two of them -- lanes 0-31 = key 8g + j over this
+      // wave's 32 queries, lanes 32-63 = key 8g + 4 + j -- and leaves through a scalar store: no vector instruction spent
+      // (32 v_writelane per tile had cost the forward what the backward gained).  Word position of key k in its tile of 32:
+      // 8 (k / 8) + 2 (k % 4) + (k / 4) % 2.
+      const uint32_t* tb = KEEP ? a.bits + ((size_t)(b * a.nh + hh) * 8 + __builtin_amdgcn_readfirstlane(wave)) * 256 + k0 : nullptr;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const czc_quad qd = czc_rng_quad(rkey, (erow + (uint32_t)(k0 + 8 * g + 4 * h)) >> 2);
-        s[4 * g + 0] = ((qd.lo & 0xffffu) >= a.thr) ? s[4 * g + 0] : 0.f;
-        s[4 * g + 1] = (qd.lo >= (a.thr << 16)) ? s[4 * g + 1] : 0.f;
-        s[4 * g + 2] = ((qd.hi & 0xffffu) >= a.thr) ? s[4 * g + 2] : 0.f;
-        s[4 * g + 3] = (qd.hi >= (a.thr << 16)) ? s[4 * g + 3] : 0.f;
+        if (!KEEP) {
+          s[4 * g + 0] = ((qd.lo & 0xffffu) >= a.thr) ? s[4 * g + 0] : 0.f;
+          s[4 * g + 1] = (qd.lo >= (a.thr << 16)) ? s[4 * g + 1] : 0.f;
+          s[4 * g + 2] = ((qd.hi & 0xffffu) >= a.thr) ? s[4 * g + 2] : 0.f;
+          s[4 * g + 3] = (qd.hi >= (a.thr << 16)) ? s[4 * g + 3] : 0.f;
+        } else {
+          const bool kp[4] = {(qd.lo & 0xffffu) >= a.thr, qd.lo >= (a.thr << 16), (qd.hi & 0xffffu) >= a.thr, qd.hi >= (a.thr << 16)};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            s[4 * g + j] = kp[j] ? s[4 * g + j] : 0.f;
+            const unsigned long long m = __ballot(kp[j]);
+            // (no "memory" clobber: nothing in this kernel reads these words, and a clobber would pin the V fragment reads
+            // of the P V product behind the sixteen stores)
+            asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(m), "s"(tb), "n"(8 * (4 * g + j)));
+          }
+        }
       }
     }
 #pragma unroll
@@ -419,6 +442,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_res_kernel(const AttnArgs a) 
       }
     if (q < S && h == 0) a.lse[((size_t)b * a.nh + hh) * S + q] = (m + __log2f(l)) * LN2;
   }
+  if (DROP && KEEP) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::: "memory");   // the scalar stores sit in the scalar cache until written back
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1066,10 +1090,15 @@ __device__ __forceinline__ bf16x8 frag_img16(const unsigned char* img, int row0,
 // arithmetic and their LDS / MFMA latencies run under it.
 // PIPE (with FULL): the S / dP products of block n+1 are issued at the top of step n, before the softmax arithmetic of block n
 // (whose scores were made a step earlier): their fragment reads and MFMA latency run under it.
-template <bool DROP, bool FULL, bool PIPE>
+// BITS (with DROP, FULL): the keep bits the forward left (AttnArgs::bits) travel through the ring, 1 KB per block (wave 7's
+// piece: the words of the block's 32 queries for all 256 keys); a lane reads the word of its key and tests bits instead of
+// hashing: the draws were a third of the vector instructions.  All 160 KB of LDS.
+template <bool DROP, bool FULL, bool PIPE, bool BITS>
 __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs a) {
-  constexpr int ST = 12544, O_LSE = 50176, O_DEL = 50688, O_DS = 51200, O_OUT = 83968, O_K = 92160, O_V = 124928, O_RED = 157696;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[159744];
+  constexpr int ST = BITS ? 13568 : 12544;   // Q 4096 | dO 4096 | O 4096 | raw lse 256 | keep words 1024
+  constexpr int O_LSE = 4 * ST, O_DEL = O_LSE + 512, O_DS = O_DEL + 512, O_OUT = O_DS + 32768, O_K = O_OUT + 8192, O_V = O_K + 32768,
+                O_RED = O_V + 32768;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[O_RED + 2048];
   const unsigned smem_lds = (unsigned)(__UINTPTR_TYPE__)(att_lptr_t)smem;   // DMA destinations are LDS byte addresses
   // Lane-constant addresses must not be hoisted out of the loops (they were: 44 registers spilled to scratch, and scratch
   // reloads are vector-memory operations that wait behind the DMA): every loop body starts from a laundered lane id.
@@ -1097,8 +1126,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
   int pf_n = 0, pf_st = 0, pf_item = blockIdx.x;
   const bf16_t *pf_q, *pf_do, *pf_o;
   const float* pf_lse;
+  const uint32_t* pf_bits = nullptr;
   auto pf_set = [&]() {
     const int b = pf_item / nh, hh = pf_item - b * nh;
+    if (BITS) pf_bits = a.bits + (size_t)pf_item * 8 * 256;
     pf_q = a.qkv + (size_t)b * S * H3 + hh * 64;
     pf_do = a.dctx + (size_t)b * S * H + hh * 64;
     pf_o = a.ctx + (size_t)b * S * H + hh * 64;
@@ -1115,7 +1146,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
     for (int j = 0; j < 2; ++j) {
       const int slot = 2 * wave + j, tsr = slot >> 2, p = slot & 3;
       const int row = 8 * p + (lane >> 3), c = (lane & 7) ^ swz64(row);
-      ring_off[j] = slot < 12 ? (unsigned)((row * (tsr == 0 ? H3 : H) + c * 8) * 2) : (unsigned)((lane & 31) * 4);
+      ring_off[j] = slot < 12 ? (unsigned)((row * (tsr == 0 ? H3 : H) + c * 8) * 2) : (slot == 14 ? (unsigned)(lane * 16) : (unsigned)((lane & 31) * 4));
       const int rk = 16 * (wave & 3) + 8 * j + (lane >> 3), ck = (lane & 7) ^ swz64(rk);
       kv_off[j] = (unsigned)((rk * H3 + ck * 8) * 2);
     }
@@ -1134,6 +1165,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
           att_dma16_s(ring_off[j], base, stg + tsr * 4096 + p * 1024);
         } else if (slot == 12) {
           att_dma4_s(ring_off[j], pf_lse + qb, stg + 12288);
+        } else if (BITS && slot == 14) {   // wave 7: the block's keep words, 64 lanes x 16 bytes
+          att_dma16_s(ring_off[j], pf_bits + pf_st * 256, stg + 12544);
         }
       }
     } else
@@ -1332,20 +1365,27 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
         }
         // rows (registers) are queries qb + 8g + 4h + j, the lane is the key
         const uint32_t ebase = ebase0 + (uint32_t)r;
+        // BITS: the word of this lane's key, bit i = query qb + i is kept; shifted so that bit 8g + j is query 8g + 4h + j
+        uint32_t kw = 0;
+        if (BITS) kw = ((const uint32_t*)(stg + 12544))[k0 + 8 * (r >> 3) + 2 * (r & 3) + ((r >> 2) & 1)] >> (4 * h);
+        const uint32_t ikb = __builtin_bit_cast(uint32_t, a.inv_keep);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4 l4 = *(const f32x4*)(&lse_b[8 * g + 4 * h]);
           const f32x4 d4 = *(const f32x4*)(&del_b[8 * g + 4 * h]);
           const f32x4 kl = kbias - l4;
           czc_quad qd = {0u, 0u};   // one RNG quad per lane, shared inside each group of four lanes (see the dK/dV kernel)
-          if (DROP) qd = czc_rng_quad(rkey, (ebase + (uint32_t)(qb + 8 * g + 4 * h + (r & 3)) * S4) >> 2);
+          if (DROP && !BITS) qd = czc_rng_quad(rkey, (ebase + (uint32_t)(qb + 8 * g + 4 * h + (r & 3)) * S4) >> 2);
           const uint32_t qlo[4] = {quad_bcast<0>(qd.lo), quad_bcast<1>(qd.lo), quad_bcast<2>(qd.lo), quad_bcast<3>(qd.lo)};
           const uint32_t qhi[4] = {quad_bcast<0>(qd.hi), quad_bcast<1>(qd.hi), quad_bcast<2>(qd.hi), quad_bcast<3>(qd.hi)};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float p = __builtin_amdgcn_exp2f(fmaf(s[4 * g + j], c2, kl[j]));
             float z = 1.f;
-            if (DROP) {
+            if (DROP && BITS) {   // sign-extended one-bit field (0 / all ones) AND the bits of 1 / (1 - p)
+              const int keep = ((int)(kw << (31 - (8 * g + j)))) >> 31;
+              z = __builtin_bit_cast(float, (uint32_t)keep & ikb);
+            } else if (DROP) {
               const uint32_t t = ((r & 2) ? qhi[j] : qlo[j]) << ((r & 1) ? 0 : 16);
               z = t >= (a.thr << 16) ? a.inv_keep : 0.f;
             }
@@ -1376,7 +1416,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
       // behind a wave's pieces of block n+2 (requested in step n-1) are at least its pieces of block n+3: two (waves 0-5),
       // one (wave 6: lse); wave 7 has no ring piece
       if (wave < 6) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else if (wave == 6) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      else if (wave == 6 || BITS) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");   // BITS: wave 7 has the keep-word piece
       ATT_STAMP(5 + 6 * st);
       ATT_BAR();
       ATT_STAMP(6 + 6 * st);
@@ -1516,6 +1556,7 @@ static int attn_check(const char* who, int B, int S, int nh, float p) {
 
 using namespace czc;
 
+static int g_attn_keep = -1;          // CZC_ATTN_KEEP_WORDS=0: the keep words are neither written nor read, the backward hashes again (A/B runs)
 static int g_attn_stream_full = -1;   // CZC_ATTN_STREAM_FULL=0: the general streaming kernel at 256 tokens too, 1: specialised without the S / dP pipeline, 2 (default): with it (A/B runs)
 static int g_attn_stream_bwd = -1;  // CZC_ATTN_STREAM_BWD=0: the one-workgroup-per-item fused backward instead of the streaming one (A/B runs)
 static int g_attn_fused_bwd = -1;   // CZC_ATTN_FUSED_BWD=0 keeps the two-kernel backward for short sequences too (A/B runs)
@@ -1532,22 +1573,35 @@ extern "C" int64_t czc_attention_bias_scratch_floats(int batch, int seq, int hea
   return (int64_t)batch * ceil_div(seq, 128) * 3 * heads * 64;
 }
 
+extern "C" int64_t czc_attention_keep_words(int batch, int seq, int heads) {
+  return seq <= 256 ? (int64_t)batch * heads * 8 * 256 : 0;
+}
+
 extern "C" int czc_attention_forward(const uint16_t* qkv, const uint8_t* mask, int batch, int seq, int heads,
                                      float dropout_p, uint32_t seed, uint32_t site, uint16_t* ctx, float* lse,
                                      czc_stream_t stream) {
+  return czc_attention_forward_keep(qkv, mask, batch, seq, heads, dropout_p, seed, site, ctx, lse, nullptr, stream);
+}
+
+extern "C" int czc_attention_forward_keep(const uint16_t* qkv, const uint8_t* mask, int batch, int seq, int heads,
+                                          float dropout_p, uint32_t seed, uint32_t site, uint16_t* ctx, float* lse,
+                                          uint32_t* keep_words, czc_stream_t stream) {
   if (int rc = attn_check("czc_attention_forward", batch, seq, heads, dropout_p)) return rc;
+  CZC_REQUIRE(!keep_words || seq <= 256, "czc_attention_forward_keep: keep words exist for seq <= 256 only (seq=%d)", seq);
   ProfScope prof((hipStream_t)stream, "attention_fwd", 4.0 * seq * (double)seq * 64.0 * heads * batch,
                  2.0 * batch * (double)seq * heads * 64.0 * 4.0);
   AttnArgs a{};
-  a.qkv = qkv; a.mask = mask; a.out = ctx; a.lse = lse;
+  if (g_attn_keep < 0) { const char* e = getenv("CZC_ATTN_KEEP_WORDS"); g_attn_keep = (e && e[0] == '0') ? 0 : 1; }
+  a.qkv = qkv; a.mask = mask; a.out = ctx; a.lse = lse; a.bits = (dropout_p > 0.f && g_attn_keep) ? keep_words : nullptr;
   a.B = batch; a.S = seq; a.nh = heads; a.H = heads * 64;
   a.thr = dropout_p > 0.f ? czc_drop_thr(dropout_p) : 0u;
   a.inv_keep = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f;
   a.seed = seed; a.site = site;
   if (seq <= 256) {   // all of K and V fit one workgroup's LDS
     dim3 grid(1, heads, batch);
-    if (a.thr) hipLaunchKernelGGL(attn_fwd_res_kernel<true>, grid, dim3(512), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(attn_fwd_res_kernel<false>, grid, dim3(512), 0, (hipStream_t)stream, a);
+    if (a.thr && a.bits) hipLaunchKernelGGL((attn_fwd_res_kernel<true, true>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    else if (a.thr) hipLaunchKernelGGL((attn_fwd_res_kernel<true, false>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((attn_fwd_res_kernel<false, false>), grid, dim3(512), 0, (hipStream_t)stream, a);
   } else {
     dim3 grid(ceil_div(seq, 128), heads, batch);
     if (a.thr) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -1561,11 +1615,22 @@ extern "C" int czc_attention_backward(const uint16_t* qkv, const uint8_t* mask, 
                                       const uint16_t* dctx, const float* lse, int batch, int seq, int heads,
                                       float dropout_p, uint32_t seed, uint32_t site, float* delta, uint16_t* dqkv,
                                       float* d_bias_qkv, float* partials, czc_stream_t stream) {
+  return czc_attention_backward_keep(qkv, mask, ctx, dctx, lse, batch, seq, heads, dropout_p, seed, site, nullptr, delta, dqkv,
+                                     d_bias_qkv, partials, stream);
+}
+
+extern "C" int czc_attention_backward_keep(const uint16_t* qkv, const uint8_t* mask, const uint16_t* ctx,
+                                           const uint16_t* dctx, const float* lse, int batch, int seq, int heads,
+                                           float dropout_p, uint32_t seed, uint32_t site, const uint32_t* keep_words,
+                                           float* delta, uint16_t* dqkv, float* d_bias_qkv, float* partials,
+                                           czc_stream_t stream) {
   if (int rc = attn_check("czc_attention_backward", batch, seq, heads, dropout_p)) return rc;
   ProfScope prof((hipStream_t)stream, "attention_bwd", 10.0 * seq * (double)seq * 64.0 * heads * batch,
                  2.0 * batch * (double)seq * heads * 64.0 * 8.0);
   AttnArgs a{};
   a.qkv = qkv; a.mask = mask; a.ctx = ctx; a.dctx = dctx; a.lse_in = lse; a.delta = delta; a.dqkv = dqkv; a.dbias = d_bias_qkv ? partials : nullptr;
+  if (g_attn_keep < 0) { const char* e = getenv("CZC_ATTN_KEEP_WORDS"); g_attn_keep = (e && e[0] == '0') ? 0 : 1; }
+  a.bits = (dropout_p > 0.f && seq <= 256 && g_attn_keep) ? const_cast<uint32_t*>(keep_words) : nullptr;
   CZC_REQUIRE(!d_bias_qkv || partials, "czc_attention_backward: d_bias_qkv needs the partials scratch");
   a.B = batch; a.S = seq; a.nh = heads; a.H = heads * 64;
   a.thr = dropout_p > 0.f ? czc_drop_thr(dropout_p) : 0u;
@@ -1585,14 +1650,15 @@ extern "C" int czc_attention_backward(const uint16_t* qkv, const uint8_t* mask, 
     dim3 gridp(items < cus ? items : cus);
     if (g_attn_stream_full < 0) { const char* e = getenv("CZC_ATTN_STREAM_FULL"); g_attn_stream_full = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }
     if (seq == 256 && g_attn_stream_full == 2) {
-      if (a.thr) hipLaunchKernelGGL((attn_bwd_stream_kernel<true, true, true>), gridp, dim3(512), 0, st, a);
-      else hipLaunchKernelGGL((attn_bwd_stream_kernel<false, true, true>), gridp, dim3(512), 0, st, a);
+      if (a.thr && a.bits) hipLaunchKernelGGL((attn_bwd_stream_kernel<true, true, true, true>), gridp, dim3(512), 0, st, a);
+      else if (a.thr) hipLaunchKernelGGL((attn_bwd_stream_kernel<true, true, true, false>), gridp, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((attn_bwd_stream_kernel<false, true, true, false>), gridp, dim3(512), 0, st, a);
     } else if (seq == 256 && g_attn_stream_full) {
-      if (a.thr) hipLaunchKernelGGL((attn_bwd_stream_kernel<true, true, false>), gridp, dim3(512), 0, st, a);
-      else hipLaunchKernelGGL((attn_bwd_stream_kernel<false, true, false>), gridp, dim3(512), 0, st, a);
+      if (a.thr) hipLaunchKernelGGL((attn_bwd_stream_kernel<true, true, false, false>), gridp, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((attn_bwd_stream_kernel<false, true, false, false>), gridp, dim3(512), 0, st, a);
     } else {
-      if (a.thr) hipLaunchKernelGGL((attn_bwd_stream_kernel<true, false, false>), gridp, dim3(512), 0, st, a);
-      else hipLaunchKernelGGL((attn_bwd_stream_kernel<false, false, false>), gridp, dim3(512), 0, st, a);
+      if (a.thr) hipLaunchKernelGGL((attn_bwd_stream_kernel<true, false, false, false>), gridp, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((attn_bwd_stream_kernel<false, false, false, false>), gridp, dim3(512), 0, st, a);
     }
     CZC_LAUNCH_CHECK();
     if (d_bias_qkv && !g_defer_partials) return czc_reduce_partials(partials, batch, 3 * a.H, 3 * a.H, d_bias_qkv, stream);

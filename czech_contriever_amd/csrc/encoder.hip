@@ -70,7 +70,7 @@ static int shape_check(const char* who, const czc_bert_shape* s) {
   return CZC_OK;
 }
 
-struct LayerWs { int64_t qkv, ctx, lse, y1, st1, x1, u, hact, y2, st2; };
+struct LayerWs { int64_t qkv, ctx, lse, keep, y1, st1, x1, u, hact, y2, st2; };   // keep: attention dropout keep words (saved passes, seq <= 256), else -1
 struct EncLayout {
   int64_t x[64 + 1];
   LayerWs layer[64];
@@ -93,6 +93,8 @@ static EncLayout enc_layout(const czc_bert_shape* s, int B, int S, int save) {
     if (save || l == 0) {
       LayerWs& w = e.layer[l];
       w.qkv = take(M * 3 * H * 2); w.ctx = take(M * H * 2); w.lse = take((int64_t)B * s->num_heads * S * 4);
+      const int64_t kw = save ? czc_attention_keep_words(B, S, s->num_heads) : 0;
+      w.keep = kw > 0 ? take(kw * 4) : -1;
       w.y1 = take(M * H * 2); w.st1 = take(M * 2 * 4); w.x1 = take(M * H * 2);
       w.u = take(M * I * 2); w.hact = take(M * I * 2); w.y2 = take(M * H * 2); w.st2 = take(M * 2 * 4);
     } else {
@@ -273,7 +275,11 @@ extern "C" int czc_encoder_forward(const czc_bert_shape* s, const float* params_
     uint16_t* y1 = BUF(w.y1) + r0 * H; uint16_t* x1 = BUF(w.x1) + r0 * H;
     uint16_t* u = BUF(w.u) + r0 * I; uint16_t* hact = BUF(w.hact) + r0 * I; uint16_t* y2 = BUF(w.y2) + r0 * H;
     RC(gemm(0, 0, EPI_BIAS, Mr, 3 * H, H, x, H, WB(CZC_P_WQKV, l), H, qkv, 3 * H, PF(CZC_P_BQKV, l), nullptr, nullptr, 1, st));
-    RC(czc_attention_forward(qkv, mask + r0, nb, seq, nh, pa, seed, SITE_ATTN(l) + sh, ctx, FBUF(w.lse) + (int64_t)b0 * nh * seq, stream));
+    // saved passes keep the dropout decisions of the probabilities as bit words for the backward (b0 == 0 there: the split
+    // last layer is for passes nothing differentiates through)
+    uint32_t* keep = (save_for_backward && w.keep >= 0 && pa > 0.f) ? (uint32_t*)(ws + w.keep) : nullptr;
+    RC(czc_attention_forward_keep(qkv, mask + r0, nb, seq, nh, pa, seed, SITE_ATTN(l) + sh, ctx, FBUF(w.lse) + (int64_t)b0 * nh * seq,
+                                  keep, stream));
     RC(gemm(0, 0, EPI_BIAS, Mr, H, H, ctx, H, WB(CZC_P_WO, l), H, y1, H, PF(CZC_P_BO, l), nullptr, nullptr, 1, st));
     RC(czc_residual_ln_forward(y1, x, Mr, H, PF(CZC_P_LN1W, l), PF(CZC_P_LN1B, l), s->layer_norm_eps, ph,
                                seed, SITE_H1(l) + sh, x1, FBUF(w.st1) + r0 * 2, stream));
@@ -382,8 +388,9 @@ extern "C" int czc_encoder_backward(const czc_bert_shape* s, const float* params
                                   SITE_H1(l), Z, Y, GF(CZC_P_LN1W, l), GF(CZC_P_LN1B, l), GF(CZC_P_BO, l), part_ln1, stream));
       RC(dweight(H, H, Y, H, BUF(w.ctx), H, GF(CZC_P_WO, l)));
       RC(dinput(EPI_STORE, M, H, H, Y, H, CZC_P_WO, l, C, H, nullptr, nullptr));
-      RC(czc_attention_backward(BUF(w.qkv), mask, BUF(w.ctx), C, FBUF(w.lse), batch, seq, nh, pa, seed, SITE_ATTN(l), delta, Q3,
-                                GF(CZC_P_BQKV, l), part_attn, stream));
+      RC(czc_attention_backward_keep(BUF(w.qkv), mask, BUF(w.ctx), C, FBUF(w.lse), batch, seq, nh, pa, seed, SITE_ATTN(l),
+                                     (w.keep >= 0 && pa > 0.f) ? (const uint32_t*)(ws + w.keep) : nullptr, delta, Q3,
+                                     GF(CZC_P_BQKV, l), part_attn, stream));
     }
     {
       const int lnr = ln_bwd_partial_rows(M);

@@ -63,6 +63,9 @@ SIGNATURES = {
     "czc_attention_forward": (i32, [vp, vp, i32, i32, i32, f32, u32, u32, vp, vp, vp]),
     "czc_attention_backward": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32, u32, u32, vp, vp, vp, vp, vp]),
     "czc_attention_bias_scratch_floats": (i64, [i32, i32, i32]),
+    "czc_attention_keep_words": (i64, [i32, i32, i32]),
+    "czc_attention_forward_keep": (i32, [vp, vp, i32, i32, i32, f32, u32, u32, vp, vp, vp, vp]),
+    "czc_attention_backward_keep": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32, u32, u32, vp, vp, vp, vp, vp, vp]),
     "czc_colsum_scratch_floats": (i64, [i32]),
     "czc_reduce_partials": (i32, [vp, i32, i32, i32, vp, vp]),
     "czc_embed_ln_forward": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, f32, u32, u32, vp, vp, vp]),
@@ -104,7 +107,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError = a symbol czc.h declares is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.czc_abi_version() != 3:
+    if lib.czc_abi_version() != 4:
         raise RuntimeError("libczc.so ABI version mismatch")
     _lib = lib
     return lib

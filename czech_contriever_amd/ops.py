@@ -41,20 +41,32 @@ def reduce_slabs(slabs, dst, accumulate):
     return dst
 
 
-def attention_forward(qkv, mask, B, S, heads, p=0.0, seed=0, site=0):
+def attention_forward(qkv, mask, B, S, heads, p=0.0, seed=0, site=0, keep_words=False):
+    """keep_words=True (seq <= 256, p > 0): also returns the dropout keep decisions as the forward's compare masks
+    (int32 words, include/czc.h) for attention_backward(..., keep_words=that tensor)."""
     ctx = torch.empty(B * S, heads * 64, dtype=BF16, device=qkv.device)
     lse = torch.empty(B, heads, S, dtype=F32, device=qkv.device)
+    if keep_words:
+        words = torch.zeros(_l().czc_attention_keep_words(B, S, heads), dtype=torch.int32, device=qkv.device)
+        L.check(_l().czc_attention_forward_keep(L.ptr(qkv, BF16), L.ptr(mask), B, S, heads, p, seed, site, L.ptr(ctx),
+                                                L.ptr(lse), L.ptr(words), L.stream_ptr()))
+        return ctx, lse, words
     L.check(_l().czc_attention_forward(L.ptr(qkv, BF16), L.ptr(mask), B, S, heads, p, seed, site, L.ptr(ctx),
                                        L.ptr(lse), L.stream_ptr()))
     return ctx, lse
 
 
-def attention_backward(qkv, mask, ctx, dctx, lse, B, S, heads, p=0.0, seed=0, site=0, d_bias=None):
+def attention_backward(qkv, mask, ctx, dctx, lse, B, S, heads, p=0.0, seed=0, site=0, d_bias=None, keep_words=None):
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(B, heads, S, dtype=F32, device=qkv.device)
     part = None
     if d_bias is not None:
         part = torch.empty(_l().czc_attention_bias_scratch_floats(B, S, heads), dtype=F32, device=qkv.device)
+    if keep_words is not None:
+        L.check(_l().czc_attention_backward_keep(L.ptr(qkv, BF16), L.ptr(mask), L.ptr(ctx, BF16), L.ptr(dctx, BF16),
+                                                 L.ptr(lse, F32), B, S, heads, p, seed, site, L.ptr(keep_words), L.ptr(delta),
+                                                 L.ptr(dqkv), L.ptr(d_bias), L.ptr(part), L.stream_ptr()))
+        return dqkv
     L.check(_l().czc_attention_backward(L.ptr(qkv, BF16), L.ptr(mask), L.ptr(ctx, BF16), L.ptr(dctx, BF16),
                                         L.ptr(lse, F32), B, S, heads, p, seed, site, L.ptr(delta), L.ptr(dqkv),
                                         L.ptr(d_bias), L.ptr(part), L.stream_ptr()))

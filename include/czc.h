@@ -30,7 +30,7 @@ extern "C" {
 #define CZC_ERR_INVALID 1
 #define CZC_ERR_HIP 2
 
-#define CZC_ABI_VERSION 3
+#define CZC_ABI_VERSION 4
 
 typedef void* czc_stream_t; /* hipStream_t */
 typedef void* czc_event_t;  /* hipEvent_t (timing disabled) */
@@ -250,6 +250,20 @@ int czc_attention_backward(const uint16_t* qkv, const uint8_t* mask, const uint1
                            const uint16_t* dctx, const float* lse, int batch, int seq, int heads,
                            float dropout_p, uint32_t seed, uint32_t site,
                            float* delta, uint16_t* dqkv, float* d_bias_qkv, float* partials, czc_stream_t stream);
+
+/* The same with the dropout keep decisions kept between the two (seq <= 256): the forward writes
+ * czc_attention_keep_words(batch, seq, heads) 32-bit words -- word [(b * heads + head) * 8 + q / 32][pos(key)] with
+ * pos(k) = 32 (k / 32) + 8 ((k % 32) / 8) + 2 (k % 4) + (k / 4) % 2, bit q % 32 set iff probability (q, key) is kept:
+ * the compare masks it forms anyway, in the order they form -- and the backward tests bits instead of regenerating the
+ * draws (a third of its vector instructions).  keep_words NULL = the plain functions above. */
+int64_t czc_attention_keep_words(int batch, int seq, int heads);
+int czc_attention_forward_keep(const uint16_t* qkv, const uint8_t* mask, int batch, int seq, int heads,
+                               float dropout_p, uint32_t seed, uint32_t site,
+                               uint16_t* ctx, float* lse, uint32_t* keep_words, czc_stream_t stream);
+int czc_attention_backward_keep(const uint16_t* qkv, const uint8_t* mask, const uint16_t* ctx,
+                                const uint16_t* dctx, const float* lse, int batch, int seq, int heads,
+                                float dropout_p, uint32_t seed, uint32_t site, const uint32_t* keep_words,
+                                float* delta, uint16_t* dqkv, float* d_bias_qkv, float* partials, czc_stream_t stream);
 
 /* x = dropout(LN(word[ids] + pos[s] + type[0]))  bf16 [M,H];  stats f32 [M,2] = (mean, rstd) */
 int czc_embed_ln_forward(const int64_t* ids, int batch, int seq, int hidden, int vocab,

@@ -428,6 +428,16 @@ def test_attention_dropout_matches_masked_reference(ops, S, B, nh):
     ref.backward(dctx.float())
     dqkv = ops.attention_backward(qkv, mask, ctx, dctx, lse, B, S, nh, p, seed, site)
     report("attn+dropout dqkv", dqkv, qv.grad, 3e-2, 2e-2)
+    if S <= 256:
+        # the keep decisions handed from the forward to the backward as bit words: the same draws, so the same numbers
+        ctx2, lse2, words = ops.attention_forward(qkv, mask, B, S, nh, p, seed, site, keep_words=True)
+        assert torch.equal(ctx2, ctx) and torch.equal(lse2, lse)
+        w = words.view(B, nh, 8, 256)
+        for b_, h_, q_, k_ in [(0, 0, 0, 0), (B - 1, nh - 1, S - 1, S - 1), (1, 0, S // 2, 3), (0, nh - 1, 33 % S, S - 2)]:
+            pos = 32 * (k_ // 32) + 8 * ((k_ % 32) // 8) + 2 * (k_ % 4) + (k_ // 4) % 2   # include/czc.h
+            assert ((int(w[b_, h_, q_ // 32, pos]) >> (q_ % 32)) & 1) == int(keep[b_, h_, q_, k_]), (b_, h_, q_, k_)
+        dq2 = ops.attention_backward(qkv, mask, ctx, dctx, lse, B, S, nh, p, seed, site, keep_words=words)
+        assert torch.equal(dq2, dqkv), float((dq2.float() - dqkv.float()).abs().max())
 
 
 # ------------------------------------------------------------------------------------------------

@@ -22,6 +22,8 @@ for rnd in range(5):
         ctx, lse = ops.attention_forward(qkv, mk, B, S, nh, p, 5, 3)
         db = torch.zeros(3 * H, device=dev)
         tf = timeit(lambda: ops.attention_forward(qkv, mk, B, S, nh, p, 5, 3))
+        if p > 0 and rnd:
+            res.setdefault(name + " fwd+keep words", []).append((timeit(lambda: ops.attention_forward(qkv, mk, B, S, nh, p, 5, 3, keep_words=True)), 0.0))
         tb = timeit(lambda: ops.attention_backward(qkv, mk, ctx, dctx, lse, B, S, nh, p, 5, 3, d_bias=db))
         if rnd: res.setdefault(name, []).append((tf, tb))
 for k, v in res.items():
