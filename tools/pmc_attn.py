@@ -11,7 +11,9 @@ qkv = (torch.randn(B * S, 3 * H, device=dev) * 0.5).to(torch.bfloat16)
 dctx = (torch.randn(B * S, H, device=dev) * 0.5).to(torch.bfloat16)
 mask = torch.ones(B, S, dtype=torch.bool, device=dev)
 db = torch.zeros(3 * H, device=dev)
-for _ in range(4):
-    ctx, lse = ops.attention_forward(qkv, mask, B, S, nh, 0.1, 5, 3)
-    ops.attention_backward(qkv, mask, ctx, dctx, lse, B, S, nh, 0.1, 5, 3, d_bias=db)
+for _ in range(4):   # as a saved encoder pass runs them: the forward keeps its dropout decisions for the backward
+    ctx, lse, words = ops.attention_forward(qkv, mask, B, S, nh, 0.1, 5, 3, keep_words=True)
+    ops.attention_backward(qkv, mask, ctx, dctx, lse, B, S, nh, 0.1, 5, 3, d_bias=db, keep_words=words)
+for _ in range(4):   # and as a pass nothing differentiates through (the key encoder)
+    ops.attention_forward(qkv, mask, B, S, nh, 0.1, 5, 3)
 torch.cuda.synchronize()
