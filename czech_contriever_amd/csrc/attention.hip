@@ -1090,7 +1090,7 @@ __device__ __forceinline__ bf16x8 frag_img16(const unsigned char* img, int row0,
 // arithmetic and their LDS / MFMA latencies run under it.
 // PIPE (with FULL): the S / dP products of block n+1 are issued at the top of step n, before the softmax arithmetic of block n
 // (whose scores were made a step earlier): their fragment reads and MFMA latency run under it.
-// BITS (with DROP, FULL): the keep bits the forward left (AttnArgs::bits) travel through the ring, 1 KB per block (wave 7's
+// BITS (with DROP): the keep bits the forward left (AttnArgs::bits) travel through the ring, 1 KB per block (wave 7's
 // piece: the words of the block's 32 queries for all 256 keys); a lane reads the word of its key and tests bits instead of
 // hashing: the draws were a third of the vector instructions.  All 160 KB of LDS.
 template <bool DROP, bool FULL, bool PIPE, bool BITS>
@@ -1173,6 +1173,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int slot = 2 * wave + j;             // 0-3 Q, 4-7 dO, 8-11 O (waves 0-5), 12 lse (wave 6); wave 7 has no ring piece
+      if (BITS && slot == 14) { att_dma16_s(ring_off[j], pf_bits + pf_st * 256, stg + 12544); continue; }   // keep words: nothing to clamp
       if (slot > 12) continue;
       if (slot < 12) {
         const int tsr = slot >> 2, p = slot & 3;
@@ -1657,7 +1658,8 @@ extern "C" int czc_attention_backward_keep(const uint16_t* qkv, const uint8_t* m
       if (a.thr) hipLaunchKernelGGL((attn_bwd_stream_kernel<true, true, false, false>), gridp, dim3(512), 0, st, a);
       else hipLaunchKernelGGL((attn_bwd_stream_kernel<false, true, false, false>), gridp, dim3(512), 0, st, a);
     } else {
-      if (a.thr) hipLaunchKernelGGL((attn_bwd_stream_kernel<true, false, false, false>), gridp, dim3(512), 0, st, a);
+      if (a.thr && a.bits) hipLaunchKernelGGL((attn_bwd_stream_kernel<true, false, false, true>), gridp, dim3(512), 0, st, a);
+      else if (a.thr) hipLaunchKernelGGL((attn_bwd_stream_kernel<true, false, false, false>), gridp, dim3(512), 0, st, a);
       else hipLaunchKernelGGL((attn_bwd_stream_kernel<false, false, false, false>), gridp, dim3(512), 0, st, a);
     }
     CZC_LAUNCH_CHECK();
