@@ -402,13 +402,15 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_res_kernel(const AttnArgs a) 
           s[4 * g + 3] = (qd.hi >= (a.thr << 16)) ? s[4 * g + 3] : 0.f;
         } else {
           const bool kp[4] = {(qd.lo & 0xffffu) >= a.thr, qd.lo >= (a.thr << 16), (qd.hi & 0xffffu) >= a.thr, qd.hi >= (a.thr << 16)};
+          typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < 4; j += 2) {
             s[4 * g + j] = kp[j] ? s[4 * g + j] : 0.f;
-            const unsigned long long m = __ballot(kp[j]);
+            s[4 * g + j + 1] = kp[j + 1] ? s[4 * g + j + 1] : 0.f;
+            const u64x2_t m = {__ballot(kp[j]), __ballot(kp[j + 1])};   // two registers' masks = four words, one store
             // (no "memory" clobber: nothing in this kernel reads these words, and a clobber would pin the V fragment reads
-            // of the P V product behind the sixteen stores)
-            asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(m), "s"(tb), "n"(8 * (4 * g + j)));
+            // of the P V product behind the stores)
+            asm volatile("s_store_dwordx4 %0, %1, %2" ::"s"(m), "s"(tb), "n"(8 * (4 * g + j)));
           }
         }
       }
