@@ -1050,6 +1050,13 @@ __device__ __forceinline__ void att_dma16_s(unsigned off, const void* base, unsi
   const unsigned l = __builtin_amdgcn_readfirstlane(dst);   // LDS byte address (wave-uniform)
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(l) : "memory", "m0");
 }
+// Two pieces to dst and dst + 1024 behind ONE write of M0: the instruction's immediate offset moves both the source and the
+// LDS address, so the second lane offset comes in 1024 bytes short (off1m = off1 - 1024).
+__device__ __forceinline__ void att_dma16_s2(unsigned off0, unsigned off1m, const void* base, unsigned dst) {
+  const unsigned l = __builtin_amdgcn_readfirstlane(dst);
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024"
+               ::"v"(off0), "v"(off1m), "s"(base), "s"(l) : "memory", "m0");
+}
 __device__ __forceinline__ void att_dma4_s(unsigned off, const void* base, unsigned dst) {
   const unsigned l = __builtin_amdgcn_readfirstlane(dst);   // LDS byte address (wave-uniform)
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(off), "s"(base), "s"(l) : "memory", "m0");
@@ -1128,14 +1135,20 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
   int pf_n = 0, pf_st = 0, pf_item = blockIdx.x;
   const bf16_t *pf_q, *pf_do, *pf_o;
   const float* pf_lse;
+  const bf16_t* pf_mine;
   const uint32_t* pf_bits = nullptr;
-  auto pf_set = [&]() {
+  auto pf_set = [&]() __attribute__((always_inline)) {
     const int b = pf_item / nh, hh = pf_item - b * nh;
     if (BITS) pf_bits = a.bits + (size_t)pf_item * 8 * 256;
     pf_q = a.qkv + (size_t)b * S * H3 + hh * 64;
     pf_do = a.dctx + (size_t)b * S * H + hh * 64;
     pf_o = a.ctx + (size_t)b * S * H + hh * 64;
     pf_lse = a.lse_in + ((size_t)b * nh + hh) * S;
+    // the tensor this wave's two ring pieces come from (waves 0-5), picked from values, not from the captured variables
+    const bf16_t* const mq = a.qkv + (size_t)b * S * H3 + hh * 64;
+    const bf16_t* const md = a.dctx + (size_t)b * S * H + hh * 64;
+    const bf16_t* const mo = a.ctx + (size_t)b * S * H + hh * 64;
+    pf_mine = wave < 2 ? mq : (wave < 4 ? md : mo);
   };
   pf_set();
   // Lane parts of the DMA source addresses, computed once on purpose (six registers): byte offsets of this lane's 16 bytes
@@ -1155,21 +1168,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
   }
   unsigned kr_off;   // this lane's key, clamped to S - 1: offset of its mask byte in a batch row
   { int kr = k0 + (lane0 & 31); if (kr > S - 1) kr = S - 1; kr_off = (unsigned)kr; }
-  auto issue_ring = [&](int lane) {   // two pieces per wave of block pf_n -> stage pf_n & 3; past the schedule's end: the last block again
+  auto issue_ring = [&](int lane) __attribute__((always_inline)) {   // two pieces per wave of block pf_n -> stage pf_n & 3; past the schedule's end: the last block again
     const unsigned stg = smem_lds + (pf_n & 3) * ST;
     const int qb = 32 * pf_st;
     if (FULL || qb + 32 <= S) {   // no row of the block is clamped: scalar bases + the precomputed lane offsets
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int slot = 2 * wave + j, tsr = slot >> 2, p = slot & 3;
-        if (slot < 12) {
-          const bf16_t* base = tsr == 0 ? pf_q + (size_t)qb * H3 : (tsr == 1 ? pf_do : pf_o) + (size_t)qb * H;
-          att_dma16_s(ring_off[j], base, stg + tsr * 4096 + p * 1024);
-        } else if (slot == 12) {
-          att_dma4_s(ring_off[j], pf_lse + qb, stg + 12288);
-        } else if (BITS && slot == 14) {   // wave 7: the block's keep words, 64 lanes x 16 bytes
-          att_dma16_s(ring_off[j], pf_bits + pf_st * 256, stg + 12544);
-        }
+      if (wave < 6) {   // a wave's two pieces are neighbours in the stage: one write of M0, the second piece by the immediate offset
+        const int tsr = wave >> 1, p = 2 * (wave & 1);
+        const bf16_t* base = pf_mine + (size_t)qb * (wave < 2 ? H3 : H);
+        att_dma16_s2(ring_off[0], ring_off[1] - 1024u, base, stg + tsr * 4096 + p * 1024);
+      } else if (wave == 6) {
+        att_dma4_s(ring_off[0], pf_lse + qb, stg + 12288);
+      } else if (BITS) {   // wave 7: the block's keep words, 64 lanes x 16 bytes
+        att_dma16_s(ring_off[0], pf_bits + pf_st * 256, stg + 12544);
       }
     } else
 #pragma unroll
@@ -1191,18 +1201,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
     ++pf_n;
     if (pf_n < total && ++pf_st == nblk) { pf_st = 0; pf_item += G; pf_set(); }
   };
-  auto issue_kv = [&](const bf16_t* qbase, int st, int lane) {   // rows 32 st + 8 (wave & 3) .. +7 of K (waves 0-3) or V (waves 4-7) of the item at qbase
+  auto issue_kv = [&](const bf16_t* qbase, int st, int lane) __attribute__((always_inline)) {   // rows 32 st + 8 (wave & 3) .. +7 of K (waves 0-3) or V (waves 4-7) of the item at qbase
     const int tsr = wave >> 2;
     const int row = 32 * st + 8 * (wave & 3) + (lane >> 3), c = (lane & 7) ^ swz64(row);
     int gr = row; if (gr > S - 1) gr = S - 1;
     att_dma16(qbase + (size_t)gr * H3 + (tsr + 1) * H + c * 8, smem_lds + (tsr ? O_V : O_K) + (32 * st + 8 * (wave & 3)) * 128);
   };
-  auto issue_kv64 = [&](const bf16_t* qbase, int grp, int lane) {   // rows 64 grp .. +63 of K (waves 0-3) and V (waves 4-7): two pieces per wave
+  auto issue_kv64 = [&](const bf16_t* qbase, int grp, int lane) __attribute__((always_inline)) {   // rows 64 grp .. +63 of K (waves 0-3) and V (waves 4-7): two pieces per wave
     const int tsr = wave >> 2;
     if (FULL || 64 * grp + 64 <= S) {
       const bf16_t* base = qbase + (size_t)(64 * grp) * H3 + (tsr + 1) * H;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) att_dma16_s(kv_off[j], base, smem_lds + (tsr ? O_V : O_K) + (64 * grp + 16 * (wave & 3) + 8 * j) * 128);
+      att_dma16_s2(kv_off[0], kv_off[1] - 1024u, base, smem_lds + (tsr ? O_V : O_K) + (64 * grp + 16 * (wave & 3)) * 128);
     } else
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -1213,7 +1222,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
     }
   };
   // delta and lse (log2 units; rows past S: +1e30, their probabilities vanish) of block m, which is step st_m of its item
-  auto delta_of = [&](int m, int st_m, int lane) {
+  auto delta_of = [&](int m, int st_m, int lane) __attribute__((always_inline)) {
     const unsigned char* sg = smem + (m & 3) * ST;
     const int row = 4 * wave + (lane >> 4), q8 = lane & 15;
     const int off = row * 128 + (((q8 >> 1) ^ swz64(row)) << 4) + 8 * (q8 & 1);
@@ -1243,7 +1252,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
   int item = blockIdx.x, b = item / nh, hh = item - b * nh;
   bf16x8 bk[4], bv[4], kT[8];
   float kbias = NEG_MASK;
-  auto take_fragments = [&](uint8_t kmask, int lane) {   // this wave's K / V rows and its 16 columns of K (all keys) from the staging area
+  auto take_fragments = [&](uint8_t kmask, int lane) __attribute__((always_inline)) {   // this wave's K / V rows and its 16 columns of K (all keys) from the staging area
     const unsigned char* kimg = smem + O_K;
     const unsigned char* vimg = smem + O_V;
     if (active) {
@@ -1255,7 +1264,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
       if (FULL || i < nblk) kT[i] = frag_img16(kimg, 32 * i, 16 * dc, lane);
     kbias = ((k0 + (lane & 31)) < S && kmask) ? 0.f : NEG_MASK;
   };
-  auto sdp_of = [&](int m, f32x16& so, f32x16& dpo, int lane) {   // S = Q K^T and dP = dO V^T of block m (stage m & 3), this wave's 32 keys
+  auto sdp_of = [&](int m, f32x16& so, f32x16& dpo, int lane) __attribute__((always_inline)) {   // S = Q K^T and dP = dO V^T of block m (stage m & 3), this wave's 32 keys
     const unsigned char* sg = smem + (m & 3) * ST;
     so = dpo = (f32x16)(0.f);
 #pragma unroll
@@ -1270,7 +1279,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
   dk[0] = dk[1] = dv[0] = dv[1] = (f32x16)(0.f);
 
   // dQ^T tile of block m from the dS ring -> bf16 image m & 1 ([32 queries][64 d], 8-byte chunks XOR (query & 15))
-  auto dq_block = [&](int m, int lane, bool live = true) {   // live = false (FULL, first step of an item): nothing is there yet, the tile is zeros
+  auto dq_block = [&](int m, int lane, bool live = true) __attribute__((always_inline)) {   // live = false (FULL, first step of an item): nothing is there yet, the tile is zeros
     const unsigned char* dsb = smem + O_DS + (m & 1) * 16384;
     f32x4 acc = (f32x4)(0.f), acc1 = (f32x4)(0.f);   // two chains (even / odd key tiles): half the dependent-MFMA latency
 #pragma unroll
@@ -1286,7 +1295,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
     *(uint2*)(smem + O_OUT + (m & 1) * 4096 + q * 128 + (((4 * dc + (lane >> 4)) ^ (q & 15)) << 3)) =
         make_uint2(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]));
   };
-  auto dq_store = [&](int m, int qb, int lane) {   // image m & 1 -> dqkv rows qb .. qb+31 of the current item, 8 bytes per thread
+  auto dq_store = [&](int m, int qb, int lane) __attribute__((always_inline)) {   // image m & 1 -> dqkv rows qb .. qb+31 of the current item, 8 bytes per thread
     const int row = 4 * wave + (lane >> 4), piece = lane & 15;
     if (qb + row < S) {
       const uint2 v = *(const uint2*)(smem + O_OUT + (m & 1) * 4096 + row * 128 + ((piece ^ (row & 15)) << 3));
@@ -1337,11 +1346,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
       const float* lse_b = lse_s + 32 * (n & 3);
       const float* del_b = del_s + 32 * (n & 3);
       const int qb = 32 * st;
-      if (!defer) issue_kv(nq, st, lane);
-      else if (st >= 1 && 2 * (st - 1) < nblk) issue_kv64(nq, st - 1, lane);
-      issue_ring(lane);
-      ATT_STAMP(1 + 6 * st);
-      if (!FULL && st > 0) dq_block(n - 1, lane);
+      // The step's stores go BEFORE its requests: vmcnt retires in order, so the counted wait at the step's end (all but the
+      // newest pieces) finds this step's requests youngest, whatever the step stores
       if (st > 1) dq_store(n - 2, qb - 64, lane);
       if (pending && 2 * st < nblk) {   // rows 64 st .. +63 of the previous item's dK and dV
         const int tid = 64 * wave + lane, row = 64 * st + (tid >> 3), c = tid & 7;
@@ -1352,6 +1358,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
           *(uint4*)(dstk + H) = *(const uint4*)(smem + O_V + off);
         }
       }
+      if (!defer) issue_kv(nq, st, lane);
+      else if (st >= 1 && 2 * (st - 1) < nblk) issue_kv64(nq, st - 1, lane);
+      issue_ring(lane);
+      ATT_STAMP(1 + 6 * st);
+      if (!FULL && st > 0) dq_block(n - 1, lane);
       ATT_STAMP(2 + 6 * st);
       if (active) {
         f32x16 s, dp;
@@ -1386,15 +1397,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream_kernel(const AttnArgs 
             const float p = __builtin_amdgcn_exp2f(fmaf(s[4 * g + j], c2, kl[j]));
             float z = 1.f;
             if (DROP && BITS) {   // sign-extended one-bit field (0 / all ones) AND the bits of 1 / (1 - p)
-              const int keep = ((int)(kw << (31 - (8 * g + j)))) >> 31;
+              int keep;   // as asm: the compiler rewrites the builtin into and + compare + select
+              asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(kw), "n"(8 * g + j));
               z = __builtin_bit_cast(float, (uint32_t)keep & ikb);
             } else if (DROP) {
               const uint32_t t = ((r & 2) ? qhi[j] : qlo[j]) << ((r & 1) ? 0 : 16);
               z = t >= (a.thr << 16) ? a.inv_keep : 0.f;
             }
-            const float dpz = z * dp[4 * g + j];
-            dp[4 * g + j] = p * (dpz - d4[j]);  // dS
-            s[4 * g + j] = p * z;               // P~
+            const float pz = p * z;                                  // P~
+            dp[4 * g + j] = fmaf(pz, dp[4 * g + j], -(p * d4[j]));   // dS = P (z dP - delta)
+            s[4 * g + j] = pz;
           }
         }
         unsigned char* my = smem + O_DS + (n & 1) * 16384 + wave * 2048 + r * 64;
