@@ -309,10 +309,18 @@ def main():
         return launch_ranks(args.gpus)
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} under a launcher with WORLD_SIZE={world}: the two must agree")
+    # CZC_BENCH_REHEARSE=1: a dry run of the N > 1 path on a box with fewer GPUs than ranks (ranks share the cards,
+    # gloo instead of RCCL, which refuses two ranks on one device).  Its line says so in `data`; it is not a measurement.
+    rehearse = world > 1 and os.environ.get("CZC_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from czech_contriever_amd import lib as L
     from czech_contriever_amd.parallel import DataParallel
@@ -432,7 +440,7 @@ def main():
             "metric": "contrastive pairs/sec (seq256, bsz256/GPU, queue131k)",
             "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic" if not rehearse else "synthetic; REHEARSAL: ranks share GPUs over gloo, not a measurement",
             "config": {"workload": "MoCo CZERT (bert-base-sized) bf16, chunk_length=256, per_gpu_batch_size=256, "
                                    "queue_size=131072, temperature=0.05" if headline else
                                    f"NON-HEADLINE diagnostic: objective={args.objective} batch={args.batch} seq={args.seq} ragged={args.ragged} queue={args.queue} dropout={not args.no_dropout}",
