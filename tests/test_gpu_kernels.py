@@ -411,7 +411,7 @@ def test_attention_backward_streaming_shapes(ops, B, S, nh, seed):
     assert torch.equal(dqkv, again)
 
 
-@pytest.mark.parametrize("S,B,nh", [(128, 2, 2), (252, 2, 2), (320, 2, 2), (128, 23, 12), (256, 2, 2), (256, 23, 12)])   # (multiples of 4: the draw index pitch is S rounded up to 4) <= 256: the single-pass backward; 320: the dQ / dK+dV kernel pair; 23 x 12 = 276 items: the persistent forward; 256: the backward's 256-token specialisation, with fewer and with more items than CUs
+@pytest.mark.parametrize("S,B,nh", [(64, 4, 12), (128, 2, 2), (252, 2, 2), (320, 2, 2), (128, 23, 12), (256, 2, 2), (256, 23, 12)])   # 64: config 1's chunk length; (multiples of 4: the draw index pitch is S rounded up to 4) <= 256: the single-pass backward; 320: the dQ / dK+dV kernel pair; 23 x 12 = 276 items: the persistent forward; 256: the backward's 256-token specialisation, with fewer and with more items than CUs
 def test_attention_dropout_matches_masked_reference(ops, S, B, nh):
     from tests.dropout_ref import keep_mask
     p, seed, site = 0.1, 7, 16
