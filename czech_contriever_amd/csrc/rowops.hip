@@ -402,7 +402,9 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(
     const bf16_t* __restrict__ dx, float* d_word, float* d_pos, float* d_type0, float* d_gamma, float* d_beta, float* part) {
   __shared__ float lds_acc[3 * 1024];
   __shared__ __attribute__((aligned(16))) float tr_all[4][1024];
+  __shared__ int order_all[4][64];
   float* tr = tr_all[threadIdx.x >> 6];
+  int* order = order_all[threadIdx.x >> 6];
   for (int i = threadIdx.x; i < 3 * 1024; i += blockDim.x) lds_acc[i] = 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -428,10 +430,56 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(
    f32x4 pacc[NIT];
 #pragma unroll
    for (int it = 0; it < NIT; ++it) pacc[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-   for (int b = b0; b < b1; ++b) {
+   // Word rows: consecutive tokens of the unit with the SAME id (the [CLS] column, runs of padding) are summed in
+   // registers and leave as one row of atomics, and a run whose incoming gradient rows are all exactly zero (padded
+   // positions: nothing attends to them and the pooling masks them, so their gradient is 0.0 all the way down) adds
+   // nothing at all.  On text-like ids the per-token form serialised on the hot rows in L2: 233 us with uniform ids,
+   // 441 us with a Zipf head, 766 us with 30 % padding (tools/bench_embed_bwd.py).
+   f32x4 wacc[NIT];
+#pragma unroll
+   for (int it = 0; it < NIT; ++it) wacc[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+   int cur_id = -1;
+   bool wany = false;
+   auto flush_word = [&]() {
+    if (cur_id >= 0 && wany) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = (lane + 64 * it) * 4;
+        if (c < H) *(f32x4*)(tr + c) = wacc[it];     // wave-private row image in LDS
+      }
+      // scatter-add with every atomic wave-instruction covering 256 CONTIGUOUS bytes (lane l -> element 64k + l):
+      // four 4-byte adds 16 B apart per lane ran at a quarter of this rate (MI355X float-atomic access shape)
+      for (int c = lane; c < H; c += 64) unsafeAtomicAdd(d_word + (size_t)cur_id * H + c, tr[c]);
+    }
+   };
+   // the unit's tokens in the order of their ids (a rank by counting, one token per lane): equal ids become neighbours,
+   // so a frequent word costs the unit one row of atomics, not one per occurrence
+   const int nu = b1 - b0;
+   const bool sorted = nu <= 64;
+   if (sorted) {
+    int64_t m64 = lane < nu ? ids[(size_t)(b0 + lane) * S + s] : 0;
+    const int mine = (int)(m64 < 0 ? 0 : (m64 >= vocab ? vocab - 1 : m64));
+    int rank = 0;
+    for (int j = 0; j < nu; ++j) {
+      const int other = __builtin_amdgcn_readlane(mine, j);
+      rank += (other < mine || (other == mine && j < lane)) ? 1 : 0;
+    }
+    if (lane < nu) order[rank] = lane;
+   }
+   for (int k = 0; k < nu; ++k) {
+    const int b = b0 + (sorted ? order[k] : k);
     const int row = b * S + s;
-    int64_t id = ids[row];
-    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    int64_t id64 = ids[row];
+    id64 = id64 < 0 ? 0 : (id64 >= vocab ? vocab - 1 : id64);
+    const int id = __builtin_amdgcn_readfirstlane((int)id64);
+    if (id != cur_id) {
+      flush_word();
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) wacc[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      cur_id = id;
+      wany = false;
+    }
+    bool nz = false;
     const size_t base = (size_t)row * H;
     const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
     f32x4 xh[NIT], gh[NIT];
@@ -445,6 +493,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(
                         *(const f32x4*)(pos + (size_t)s * H + c);
         xh[it] = (z - mean) * rstd;
         f32x4 g = ld_bf4(dx + base + c);
+        nz = nz || g[0] != 0.f || g[1] != 0.f || g[2] != 0.f || g[3] != 0.f;
         if (thr) g *= drop_scale4(seed, site, (uint32_t)(base + c), thr, inv_keep);
         acc[0][it] += g * xh[it];
         acc[1][it] += g;
@@ -462,13 +511,12 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(
         const f32x4 dz = (gh[it] - s1 - xh[it] * s2) * rstd;
         acc[2][it] += dz;
         pacc[it] += dz;
-        *(f32x4*)(tr + c) = dz;     // wave-private row image in LDS
+        wacc[it] += dz;
       }
     }
-    // scatter-add with every atomic wave-instruction covering 256 CONTIGUOUS bytes (lane l -> element 64k + l):
-    // four 4-byte adds 16 B apart per lane ran at a quarter of this rate (MI355X float-atomic access shape)
-    for (int c = lane; c < H; c += 64) unsafeAtomicAdd(d_word + (size_t)id * H + c, tr[c]);
+    wany = wany || __any(nz);
    }
+   flush_word();
    if (b1 > b0) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {

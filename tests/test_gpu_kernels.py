@@ -207,6 +207,40 @@ def test_embed_ln_fwd_bwd(ops):
     report("d_beta", db, bp.grad, 2e-3, 1e-3)
 
 
+@pytest.mark.parametrize("B", [40, 300])   # 40: chunks of 2-3 sequences per unit; 300: sixteen chunks of 19 per position
+def test_embed_ln_bwd_equal_id_runs_and_padding(ops, B):
+    """Text-shaped ids: every sequence starts with the same id (runs of equal ids inside a unit are summed before the
+    scatter-add), padded tails (id 0) carry an exactly-zero incoming gradient (their rows add nothing), a frequent id
+    in the middle; and the gradients ACCUMULATE into what is already there (update_freq > 1)."""
+    S, H, V = 24, 768, 500
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(5, V, (B, S), generator=g)
+    ids[:, 0] = 3
+    ids[:, 7] = torch.where(torch.rand(B, generator=g) < 0.6, torch.tensor(9), ids[:, 7])
+    lens = torch.randint(9, S + 1, (B,), generator=g)
+    valid = torch.arange(S)[None, :] < lens[:, None]
+    ids = torch.where(valid, ids, torch.zeros_like(ids)).to(dev())
+    valid = valid.to(dev())
+    word, pos, typ = rnd(V, H, seed=1, scale=0.05), rnd(64, H, seed=2, scale=0.05), rnd(2, H, seed=3, scale=0.05)
+    gamma, beta = 1.0 + 0.1 * rnd(H, seed=4), 0.1 * rnd(H, seed=5)
+    x, stats = ops.embed_ln_forward(ids, word, pos, typ[0].contiguous(), gamma, beta, 1e-12)
+    wp, pp, tp = (t.clone().requires_grad_(True) for t in (word, pos, typ))
+    gp, bp = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(wp[ids] + tp[0][None, None] + pp[:S][None], (H,), gp, bp, 1e-12)
+    dx = (rnd(B * S, H, seed=6).view(B, S, H) * valid[..., None]).to(BF16).view(B * S, H).contiguous()
+    ref.backward(dx.float().view(B, S, H))
+    start = 0.25
+    dw, dp, dt = torch.full_like(word, start), torch.full_like(pos, start), torch.full((H,), start, device=dev())
+    dg, db = torch.full((H,), start, device=dev()), torch.full((H,), start, device=dev())
+    ops.embed_ln_backward(ids, word, pos, typ[0].contiguous(), gamma, stats, dx, dw, dp, dt, dg, db)
+    report("d_word", dw - start, wp.grad, 2e-3, 1e-3)
+    report("d_pos", dp - start, pp.grad, 2e-3, 1e-3)
+    report("d_type0", dt - start, tp.grad[0], 5e-3, 1e-3)
+    report("d_gamma", dg - start, gp.grad, 5e-3, 1e-3)
+    report("d_beta", db - start, bp.grad, 5e-3, 1e-3)
+    assert torch.equal(dw[0], torch.full((H,), start, device=dev()))     # the padding id's row was not touched
+
+
 @pytest.mark.parametrize("pooling,normalize", [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_pool_fwd_bwd(ops, pooling, normalize):
     B, S, H = 5, 24, 768
