@@ -227,13 +227,13 @@ __device__ __forceinline__ void gelu8(const float (&x)[8], float (&out)[8], floa
 #undef CZC_HORNER
   float v[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = t[i] * p[i];                      // Phi - 0.5
+  for (int i = 0; i < 8; ++i) v[i] = fmaf(t[i], p[i], 0.5f);           // Phi (one rounding of 2^-25 at most: far below bf16)
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    if (MODE == 0 || MODE == 2) out[i] = fmaf(x[i], v[i], 0.5f * x[i]);
-    if (MODE == 1) out[i] = fmaf(t[i], e[i], v[i] + 0.5f);
-    if (MODE == 2) out2[i] = fmaf(t[i], e[i], v[i] + 0.5f);
+  for (int i = 0; i < 8; ++i) {                                         // 3 operations for both outputs (were 5)
+    if (MODE == 0 || MODE == 2) out[i] = x[i] * v[i];
+    if (MODE == 1) out[i] = fmaf(t[i], e[i], v[i]);
+    if (MODE == 2) out2[i] = fmaf(t[i], e[i], v[i]);
   }
 }
 __device__ __forceinline__ float dgelu_f(float x) {

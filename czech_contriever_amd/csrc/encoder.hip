@@ -93,7 +93,8 @@ static EncLayout enc_layout(const czc_bert_shape* s, int B, int S, int save) {
     if (save || l == 0) {
       LayerWs& w = e.layer[l];
       w.qkv = take(M * 3 * H * 2); w.ctx = take(M * H * 2); w.lse = take((int64_t)B * s->num_heads * S * 4);
-      const int64_t kw = save ? czc_attention_keep_words(B, S, s->num_heads) : 0;
+      // keep words only where a saved pass can draw attention dropout at all (a shape with attn_dropout 0 never writes them)
+      const int64_t kw = (save && s->attn_dropout > 0.f) ? czc_attention_keep_words(B, S, s->num_heads) : 0;
       w.keep = kw > 0 ? take(kw * 4) : -1;
       w.y1 = take(M * H * 2); w.st1 = take(M * 2 * 4); w.x1 = take(M * H * 2);
       w.u = take(M * I * 2); w.hact = take(M * I * 2); w.y2 = take(M * H * 2); w.st2 = take(M * 2 * 4);

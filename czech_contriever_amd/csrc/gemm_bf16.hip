@@ -758,10 +758,23 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
       const int i = ps * TMP + ii;
       const int rl = 16 * ii + mrow;   // row inside this pass's slice
       const float rv = (EPI == EPI_SOFTGRAD) ? rvv[i] : 0.f;
+      if (EPI == EPI_BIAS_GELU1) {
+        // one output: gelu on the fp32 values, before the staging (no unpacking of the staged bf16 pre-activation and
+        // one rounding less; the two-output form below needs u itself rounded once for both results)
+        static_assert(EPI != EPI_BIAS_GELU1 || TN % 2 == 0, "gelu8 takes two column groups at a time");
+#pragma unroll
+        for (int j = 0; j < TN; j += 2) {
+          const f32x4 v0 = acc[i][j] + bv[j], v1 = acc[i][j + 1] + bv[j + 1];
+          float xin[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]}, gl[8], dg[8];
+          gelu8<0>(xin, gl, dg);
+          acc[i][j] = (f32x4){gl[0], gl[1], gl[2], gl[3]};
+          acc[i][j + 1] = (f32x4){gl[4], gl[5], gl[6], gl[7]};
+        }
+      }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         f32x4 v = acc[i][j];
-        if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU1) v += bv[j];
+        if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) v += bv[j];
         if (EPI == EPI_SOFTGRAD) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = __expf(v[r] * a.alpha - rv) - a.beta;
@@ -786,23 +799,20 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
       const int m = row0 + wm * TM * 16 + (it * 64 + lane) / NCH;
       const unsigned off = seg_off(it);
       const u32x4 v = sv[itp];
-      if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU1) {
+      if (EPI == EPI_BIAS_GELU) {
         // two outputs: C = gelu'(u) -- all the backward needs of the pre-activation (dX = dH . gelu'(u); dW1 reads x1, dW2
         // reads h), so its epilogue is a multiply instead of a second exp / rcp / polynomial per element -- and C2 = gelu(u)
         float xin[8], gl[8], dg[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { xin[2 * e] = bflo(v[e]); xin[2 * e + 1] = bfhi(v[e]); }
-        if (EPI == EPI_BIAS_GELU) gelu8<2>(xin, gl, dg);
-        else gelu8<0>(xin, gl, dg);
+        gelu8<2>(xin, gl, dg);
         u32x4 g;
-        if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) g[e] = pack2bf(dg[2 * e], dg[2 * e + 1]);
-          __builtin_amdgcn_raw_buffer_store_b128(g, rc, off, 0, 0);
-        }
+        for (int e = 0; e < 4; ++e) g[e] = pack2bf(dg[2 * e], dg[2 * e + 1]);
+        __builtin_amdgcn_raw_buffer_store_b128(g, rc, off, 0, 0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) g[e] = pack2bf(gl[2 * e], gl[2 * e + 1]);
-        __builtin_amdgcn_raw_buffer_store_b128(g, EPI == EPI_BIAS_GELU ? rc2 : rc, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(g, rc2, off, 0, 0);
       } else if (EPI == EPI_DGELU) {
         const u32x4 u = au[it];   // gelu'(pre-activation), as the forward stored it
         u32x4 g;
@@ -1005,7 +1015,7 @@ extern "C" int czc_gemm_bf16(int a_layout, int b_layout, int epilogue, int M, in
                              const uint16_t* A, int lda, const uint16_t* B, int ldb,
                              void* C, int ldc, const float* bias, const uint16_t* aux, void* C2,
                              int splitk, czc_stream_t stream) {
-  CZC_REQUIRE(epilogue >= 0 && epilogue <= EPI_F32, "czc_gemm_bf16: epilogue %d", epilogue);
+  CZC_REQUIRE((epilogue >= 0 && epilogue <= EPI_F32) || epilogue == EPI_BIAS_GELU1, "czc_gemm_bf16: epilogue %d", epilogue);
   GemmArgs a{};
   a.A = A; a.B = B; a.C = C; a.C2 = C2; a.bias = bias; a.aux = aux;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;

@@ -72,10 +72,10 @@ def _numel(shape):
 class FlatBertEncoder(nn.Module):
     """BERT encoder + pooling whose arithmetic runs in libczc.so.  Subclassed by src.contriever.Contriever."""
 
-    _instances = 0          # every encoder of the process gets its own dropout salt, in construction order
-    _skip_init = False      # set around the constructor call of __deepcopy__: the copy's weights are overwritten anyway
+    _instances = 0          # default dropout salt of an encoder nobody has given one: construction order in the process
 
-    def __init__(self, config, pooling: str = "average"):
+    def __init__(self, config, pooling: str = "average", _init: bool = True):
+        """_init=False (used by __deepcopy__): the weights are about to be overwritten, draw nothing from the torch RNG."""
         super().__init__()
         self.config = config
         if not hasattr(config, "pooling"):
@@ -102,9 +102,10 @@ class FlatBertEncoder(nn.Module):
         self._ws: Dict[tuple, torch.Tensor] = {}
         self._ws_pool: Dict[tuple, list] = {}
         self._scratch = None
-        self._call = 0
-        self._salt = FlatBertEncoder._instances   # deterministic per process: encoder_q 0, its key copy 1, ...
-        FlatBertEncoder._instances += 1
+        self._call = 0                            # forwards so far (activation-lease stamp)
+        self._drop_calls = 0                      # TRAINING forwards so far: with `_salt`, the dropout stream's position.
+        self._salt = FlatBertEncoder._instances   # Owners that checkpoint set both (dropout_state / load_dropout_state):
+        FlatBertEncoder._instances += 1           # MoCo pins encoder_q to salt 0 and encoder_k to 1 whatever was built before
         self._anchor = None
         self._pre_grad_access = []  # callables() run before the main stream touches the flat gradient array (comm wait)
         self._post_backward = []  # callables(enc) run right after the backward has been enqueued
@@ -121,7 +122,7 @@ class FlatBertEncoder(nn.Module):
             prm = nn.Parameter(self._flat[off:off + _numel(shape)].view(shape))
             node.register_parameter(parts[-1], prm)
             self._plist.append(prm)
-        if not FlatBertEncoder._skip_init:
+        if _init:
             self.reset_parameters()
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_mirror())
 
@@ -166,11 +167,9 @@ class FlatBertEncoder(nn.Module):
 
     def __deepcopy__(self, memo):
         import copy
-        FlatBertEncoder._skip_init = True     # no random init of the copy: it would consume the torch RNG the reference
-        try:                                  # draws the initial queue from right after copy.deepcopy (src/moco.py:209-219)
-            new = self.__class__(copy.deepcopy(self.config, memo))
-        finally:
-            FlatBertEncoder._skip_init = False
+        # no random init of the copy: it would consume the torch RNG the reference draws the initial queue from right
+        # after copy.deepcopy (src/moco.py:209-219)
+        new = self.__class__(copy.deepcopy(self.config, memo), _init=False)
         new.to(self._flat.device)
         with torch.no_grad():
             new._flat.copy_(self._flat)
@@ -291,6 +290,14 @@ class FlatBertEncoder(nn.Module):
             self._scratch = torch.empty(n, dtype=torch.uint8, device=self._flat.device)
         return self._scratch
 
+    # ---- dropout stream position (checkpointed by src.utils.save / restored by src.utils.load) ----
+    def dropout_state(self) -> dict:
+        return {"salt": int(self._salt), "calls": int(self._drop_calls)}
+
+    def load_dropout_state(self, state: dict):
+        self._salt = int(state.get("salt", self._salt))
+        self._drop_calls = int(state.get("calls", self._drop_calls))
+
     def _pool_code(self):
         p = getattr(self.config, "pooling", "average")
         if p == "average":
@@ -322,10 +329,13 @@ class FlatBertEncoder(nn.Module):
     def _forward_impl(self, ids, mask, normalize, save, split=None):
         B, S = ids.shape
         self._call += 1
+        if self.training:
+            self._drop_calls += 1
         ws = self._lease_activations(B, S, self._call) if save else self._workspace(B, S, False)
         emb = torch.empty(B, self.config.hidden_size, dtype=F32, device=ids.device)
-        # (--seed, encoder, call): the same run draws the same masks; query and key encoder never share a stream of draws
-        seed = (torch.initial_seed() * 2654435761 + self._call * 40503 + (self._salt + 1) * 0x9E3779B1) & 0xFFFFFFFF
+        # (--seed, encoder, training forward): the same run draws the same masks, a resumed run continues the stream
+        # (dropout_state() travels in the checkpoint); query and key encoder never share a stream of draws
+        seed = (torch.initial_seed() * 2654435761 + self._drop_calls * 40503 + (self._salt + 1) * 0x9E3779B1) & 0xFFFFFFFF
         n_split, ev = (0, None) if (split is None or save) else (int(split[0]), split[1])
         L.check(L.load().czc_encoder_forward(
             C.byref(self._shape), self._flat.data_ptr(), self.mirror().data_ptr(), ids.data_ptr(), mask.data_ptr(),

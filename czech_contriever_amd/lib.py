@@ -165,4 +165,4 @@ def shape_struct(cfg, hidden_dropout=None, attn_dropout=None) -> BertShape:
 P_KINDS = ["WQKV", "WO", "W1", "W2", "BQKV", "BO", "LN1W", "LN1B", "B1", "B2", "LN2W", "LN2B",
            "WORD", "POS", "TYPE", "ELNW", "ELNB"]
 P = {k: i for i, k in enumerate(P_KINDS)}
-EPI = {"store": 0, "bias": 1, "bias_gelu": 2, "dgelu": 3, "add": 4, "f32": 5}
+EPI = {"store": 0, "bias": 1, "bias_gelu": 2, "dgelu": 3, "add": 4, "f32": 5, "bias_gelu_only": 8}

@@ -81,6 +81,9 @@ class FusedAdamW(torch.optim.Optimizer):
                     fn()
                 launch(n_mat, n, 0)
             else:
+                if split:                          # no split point in this array: the tail all-reduce must have finished first
+                    for fn in self._pre_tail:
+                        fn()
                 launch(0, n, n_mat)
             enc.mark_mirror_fresh()
             for p in enc._plist:

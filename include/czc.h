@@ -207,6 +207,8 @@ int czc_cast_bf16(const float* src, uint16_t* dst, int64_t n, czc_stream_t strea
 #define CZC_EPI_DGELU 3      /* C = acc * aux[m][n]  (aux = the gelu'(u) CZC_EPI_BIAS_GELU stored) */
 #define CZC_EPI_ADD 4        /* C = acc + aux[m][n] */
 #define CZC_EPI_F32 5        /* C f32 [splitk][M][ldc] = partial acc (no reduction) */
+#define CZC_EPI_BIAS_GELU_ONLY 8 /* C = gelu(acc + bias), evaluated on the fp32 sum (passes nothing differentiates through:
+                                  * the key encoder, inference); K-major operands only.  6, 7, 9 are internal (head, index) */
 
 /* C[M,N] = A . B over K.  bf16 in, fp32 accumulate.  ld* in elements.  aux/C2 share ldc.
  * splitk > 1 only with CZC_EPI_F32 (slab z at C + z*M*ldc). */

@@ -17,7 +17,7 @@ from czech_contriever_amd.engine import FlatBertEncoder
 
 class Contriever(FlatBertEncoder):
     def __init__(self, config, pooling="average", **kwargs):
-        super().__init__(config, pooling=pooling)
+        super().__init__(config, pooling=pooling, _init=kwargs.pop("_init", True))
         self._emb_dtype = torch.float32
 
     def half(self):

@@ -33,6 +33,7 @@ class InBatch(nn.Module):
                                                         random_init=opt.random_init)
         self.tokenizer = tokenizer
         self.encoder = retriever
+        self.encoder.load_dropout_state({"salt": 0})   # the dropout stream belongs to the role, not to construction order
 
     def _load_retriever(self, model_id, pooling, random_init):
         if "xlm" in model_id:
@@ -46,6 +47,10 @@ class InBatch(nn.Module):
 
     def get_encoder(self):
         return self.encoder
+
+    def set_dropout_position(self, micro_steps_done: int):
+        """see MoCo.set_dropout_position: the one encoder embeds queries and keys, two training forwards per micro-step"""
+        self.encoder.load_dropout_state({"calls": 2 * int(micro_steps_done)})
 
     def forward(self, q_tokens, q_mask, k_tokens, k_mask, stats_prefix="", iter_stats={}, **kwargs):
         bsz = len(q_tokens)

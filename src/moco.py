@@ -118,6 +118,10 @@ class MoCo(nn.Module):
         self.encoder_k = copy.deepcopy(retriever)
         for param_k in self.encoder_k.parameters():
             param_k.requires_grad = False
+        # dropout streams pinned to the role, not to how many encoders the process built before (a teacher, a temporary
+        # Contriever): query encoder 0, key encoder 1; their position is checkpointed (src.utils.save, key "czc")
+        self.encoder_q.load_dropout_state({"salt": 0})
+        self.encoder_k.load_dropout_state({"salt": 1})
 
         self.register_buffer("queue", nn.functional.normalize(torch.randn(opt.projection_size, self.queue_size), dim=0))
         self.register_buffer("queue_ptr", torch.zeros(1, dtype=torch.long))
@@ -162,6 +166,13 @@ class MoCo(nn.Module):
 
     def get_encoder(self, return_encoder_k=False):
         return self.encoder_k if return_encoder_k else self.encoder_q
+
+    def set_dropout_position(self, micro_steps_done: int):
+        """A resumed run continues the dropout streams where the checkpointed run stood instead of replaying the masks of
+        steps 0..n: each encoder draws one mask set per training forward, i.e. per micro-step (train.py calls this with
+        step * update_freq after utils.load; the checkpoint keeps the reference's five keys)."""
+        self.encoder_q.load_dropout_state({"calls": int(micro_steps_done)})
+        self.encoder_k.load_dropout_state({"calls": int(micro_steps_done)})
 
     # ------------------------------------------------------------------------------------------
     def _queue_mirror(self):

@@ -1,5 +1,7 @@
 """`--normalize_text` for the MI355X path: the character clean-up the reference applies to passages and queries before
-tokenisation (its src/normalize_text.py, `normalize(text)`; the rule set is ChemDataExtractor's, MIT).
+tokenisation (its src/normalize_text.py, `normalize(text)`).  The rule set is ChemDataExtractor's
+(chemdataextractor.text.normalize, Copyright 2016 by Matt Swain, MIT license: the copyright and permission notice are
+kept in THIRD_PARTY_NOTICES.md at the repository root).
 
 Behaviour, pinned code point by code point against the reference's own function (tests/golden/g14_text.json, made by
 oracle/make_golden_text.py): C0 controls other than the white-space ones vanish, VT / FF / NEL become a space, every

@@ -319,6 +319,8 @@ def test_gemm_epilogues(ops):
     ref_h.sum().backward()
     report("gelu(u)", h, ref_h.detach(), 1e-2, 8e-3)
     report("gelu'(u)", dg, u.grad, 1e-2, 8e-3)
+    # the one-output form (key encoder, inference) evaluates gelu on the fp32 sum, as the reference does
+    report("gelu only", ops.gemm(A, Bm, epilogue="bias_gelu_only", bias=bias), torch.nn.functional.gelu(acc + bias), 1e-2, 8e-3)
     # its backward: C = acc * aux, aux = the stored derivative
     report("dgelu", ops.gemm(A, Bm, epilogue="dgelu", aux=aux), acc.to(BF16).float() * aux.float(), 5e-2, 1e-2)
     report("add", ops.gemm(A, Bm, epilogue="add", aux=aux), acc.to(BF16).float() + aux.float(), 5e-2, 8e-3)
@@ -338,6 +340,7 @@ def test_gemm_workgroups_walking_over_tiles(ops, al, bl):
     cases = [("store", {}), ("bias", dict(bias=bias)), ("add", dict(aux=aux)), ("dgelu", dict(aux=aux))]
     if al == 0 and bl == 0:
         cases.append(("bias_gelu", dict(bias=bias)))
+        cases.append(("bias_gelu_only", dict(bias=bias)))
     lib = L.load()
     for epi, kw in cases:
         outs = []

@@ -429,3 +429,41 @@ def test_key_encoder_split_last_layer_is_bitwise_neutral(gpu, shape_kw, B, S, le
         L.check(L.load().czc_encoder_forward(ctypes.byref(enc._shape), enc._flat.data_ptr(), enc.mirror().data_ptr(), ids.data_ptr(),
                                              mask.data_ptr(), B, S, 0, 0, 0, 0, 1, enc._workspace(B, S, True).data_ptr(),
                                              enc._workspace(B, S, True).numel(), whole.data_ptr(), B // 2, None, L.stream_ptr()))
+
+
+@pytest.mark.parametrize("B,S,lengths", [(3, 27, [27, 13, 1]), (2, 200, [200, 77]), (5, 64, [64, 2, 33, 64, 17])])
+def test_dropout_backward_never_reads_unwritten_workspace(gpu, B, S, lengths):
+    """the forward of a saved pass hands the backward its attention-dropout keep decisions as bit words in the
+    activation workspace, and skips whole query blocks beyond a sequence's padded length (their words stay unwritten).
+    The backward must never read what the forward did not write: with the workspace pre-filled with 0xFF bytes and with
+    0x00 bytes, at odd lengths below 256 and dropout on, embeddings and every gradient must come out bit-identical
+    (weight matrices) / equal to the atomics' rounding (vectors and embeddings)."""
+    shape_kw = dict(TINY, max_position_embeddings=256)
+    from src.contriever import Contriever, bert_config
+    cfg = bert_config(vocab_size=shape_kw["vocab_size"], hidden_size=shape_kw["hidden_size"],
+                      num_hidden_layers=shape_kw["num_hidden_layers"], num_attention_heads=shape_kw["num_attention_heads"],
+                      intermediate_size=shape_kw["intermediate_size"], max_position_embeddings=256,
+                      hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.25)
+    enc = Contriever(cfg, pooling="average")
+    enc.load_state_dict(O.make_params(O.BertShape(**shape_kw), 91), strict=True)
+    enc = enc.cuda().train()
+    ids, mask = ragged_batch(B, S, 9100, shape_kw["vocab_size"], lengths)
+    ids, mask = ids.to(gpu), mask.to(gpu)
+    w = O.det_uniform((B, shape_kw["hidden_size"]), 92).to(gpu)
+    outs = []
+    for fill in (0xFF, 0x00):
+        enc.zero_grad(set_to_none=True)
+        enc._ws_pool.clear()
+        enc._workspace(B, S, True).fill_(fill)          # the buffer the next differentiable forward leases
+        enc._drop_calls = 0                             # the same dropout stream for both passes
+        emb = enc(input_ids=ids, attention_mask=mask, normalize=True)
+        (emb * w).sum().backward()
+        torch.cuda.synchronize()
+        outs.append((emb.detach().clone(), enc.flat_grads().clone()))
+    (e0, g0), (e1, g1) = outs
+    assert torch.isfinite(g0).all() and torch.isfinite(g1).all()
+    assert torch.equal(e0, e1)
+    nm = enc._n_mat
+    assert torch.equal(g0[:nm], g1[:nm])                                   # split-K weight gradients: fixed summation order
+    scale = float(g0[nm:].abs().max()) + 1e-12
+    assert float((g0[nm:] - g1[nm:]).abs().max()) <= 1e-5 * scale          # fp32 atomics: order-dependent last bits only

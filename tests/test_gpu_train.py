@@ -45,7 +45,17 @@ def test_train_cli_runs_saves_and_resumes(tmp_path, monkeypatch):
     assert c4["optimizer"]["state"][0]["step"] == 4
     # auto-resume: the output directory exists -> continues from `latest` up to the new total_steps
     args2 = [a if a != "4" else "6" for a in args]
+    seen = {}
+    loop = train.train
+
+    def spy(opt, model, optimizer, scheduler, step):
+        m = model.module if hasattr(model, "module") else model
+        seen.update(q=m.encoder_q.dropout_state(), k=m.encoder_k.dropout_state(), step=step)
+        return loop(opt, model, optimizer, scheduler, step)
+    monkeypatch.setattr(train, "train", spy)
     train.main(args2)
+    # the resumed run continues the dropout streams where step 4 stood (8 micro-steps) instead of replaying steps 0..3
+    assert seen == {"q": {"salt": 0, "calls": 8}, "k": {"salt": 1, "calls": 8}, "step": 4}
     c6 = torch.load(os.path.join(ck, "step-6", "checkpoint.pth"), map_location="cpu", weights_only=False)
     assert c6["step"] == 6
     # like the reference, a resumed run keeps the CHECKPOINT's schedule (utils.load builds the optimizer from

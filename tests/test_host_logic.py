@@ -141,3 +141,34 @@ def test_mirror_goes_stale_on_any_parameter_write():
     state = torch.get_rng_state()
     copy.deepcopy(enc)
     assert torch.equal(torch.get_rng_state(), state)       # the copy draws nothing from the torch RNG
+
+
+def test_dropout_stream_is_pinned_to_roles_and_resumable(tmp_path):
+    """the dropout seed is (--seed, salt, training forwards so far).  The salt belongs to the role (MoCo:
+    query 0, key 1; InBatch: 0) whatever other encoders the process built first, and a resumed run is put at the
+    position the checkpointed run stood at (train.py: step * update_freq micro-steps), so it continues the stream
+    instead of replaying the masks of steps 0..n.  The checkpoint keeps the reference's five keys."""
+    import json
+    import types
+    from src import inbatch, moco
+    from src.contriever import Contriever, bert_config
+    d = tmp_path / "m"
+    d.mkdir()
+    cfg = dict(vocab_size=64, hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=64,
+               max_position_embeddings=16)
+    (d / "config.json").write_text(json.dumps(cfg))
+    opt = types.SimpleNamespace(queue_size=8, momentum=0.9, temperature=1.0, label_smoothing=0.0, norm_doc=False,
+                                norm_query=False, moco_train_mode_encoder_k=False, weight_decay=0.01,
+                                weight_decay_from_init=False, retriever_model_id=str(d), pooling="average",
+                                random_init=True, projection_size=64)
+    Contriever(bert_config(**cfg))          # a "teacher" built first must not shift the students' salts
+    m = moco.MoCo(opt)
+    assert m.encoder_q.dropout_state() == {"salt": 0, "calls": 0}
+    assert m.encoder_k.dropout_state() == {"salt": 1, "calls": 0}
+    m.set_dropout_position(14)              # e.g. step 7 at update_freq 2
+    assert m.encoder_q.dropout_state() == {"salt": 0, "calls": 14}
+    assert m.encoder_k.dropout_state() == {"salt": 1, "calls": 14}
+    assert not any("extra_state" in k for k in m.state_dict())       # the reference's state_dict keys are untouched
+    ib = inbatch.InBatch(opt)
+    ib.set_dropout_position(3)
+    assert ib.encoder.dropout_state() == {"salt": 0, "calls": 6}     # queries and keys: two training forwards per micro-step

@@ -204,6 +204,9 @@ def main(argv=None):
             step = 0
         logger.info(f"Model loaded from {opt.model_path}")
     logger.info(utils.get_parameters(model))
+    if step > 0:   # resumed: continue the counter-based dropout streams instead of replaying the masks of steps 0..n
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        model.set_dropout_position(step * max(1, opt.target_batch_size // (opt.per_gpu_batch_size * world)))
 
     if dist.is_initialized():
         from czech_contriever_amd.parallel import DataParallel
