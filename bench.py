@@ -363,6 +363,8 @@ def main():
         model.zero_grad()
         return loss
 
+    if os.environ.get("CZC_GEMM_CFG"):   # tuning A/B only (czc_gemm_set_tile, include/czc.h)
+        L.check(lib.czc_gemm_set_tile(int(os.environ["CZC_GEMM_CFG"])))
     for i in range(args.warmup):
         last = step(i)
         torch.cuda.synchronize()

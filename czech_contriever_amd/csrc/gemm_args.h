@@ -17,6 +17,7 @@ struct GemmArgs {
   int group_n;           // column tiles per sweep of the tile order (swizzle_tile)
   int ktiles_per_split;  // K tiles handled by one split
   int fast_addr;         // both operands span < 2 GiB: DMA pieces may use 32-bit lane offsets from a scalar base
+  int store_pol;         // cache policy of the bf16 output stores: 0 plain, 1 sc1, 2 nt
   int cfg;               // tile configuration: 0 = default, 1 = 256x256 (8 waves), 2 = 128x128 (4 waves, 2 WG/CU)
   float alpha;           // head: 1/T
   float beta;            // head: eps/(K+1)

@@ -110,6 +110,10 @@ class MoCo(nn.Module):
         self.weight_decay = opt.weight_decay
         self.weight_decay_from_init = opt.weight_decay_from_init
         self.key_gather_split = True   # data parallel: last key-encoder layer in two halves, first half's all-gather under it
+        # one GPU: the key encoder's pass (EMA + forward, nothing differentiates through it) is independent of the query
+        # encoder's forward; on a second HIP stream the two passes' kernels fill each other's launch gaps and tails
+        self.key_overlap = os.environ.get("CZC_KEY_OVERLAP", "0") == "1"
+        self._key_stream = None
 
         retriever, tokenizer = self._load_retriever(opt.retriever_model_id, pooling=opt.pooling,
                                                     random_init=opt.random_init)
@@ -237,15 +241,33 @@ class MoCo(nn.Module):
 
     def _step(self, q_tokens, q_mask, k_tokens, k_mask, process_group, stats_prefix, iter_stats):
         bsz = q_tokens.size(0)
-        q = self.encoder_q(input_ids=q_tokens, attention_mask=q_mask, normalize=self.norm_query)
-
         w = dist_utils.get_world_size(process_group)
         kx = self._exchange(process_group) if w > 1 else None
+        side = None
+        if self.key_overlap and kx is None and q_tokens.is_cuda:
+            main = torch.cuda.current_stream()
+            if self._key_stream is None or self._key_stream.device != q_tokens.device:
+                self._key_stream = torch.cuda.Stream(device=q_tokens.device)
+            side = self._key_stream
+            side.wait_stream(main)      # the optimizer's update of the query weights, the previous enqueue
+            with torch.cuda.stream(side), torch.no_grad():
+                self._momentum_update_key_encoder()
+                if not self.encoder_k.training and not self.moco_train_mode_encoder_k:
+                    self.encoder_k.eval()
+                k = self.encoder_k(input_ids=k_tokens, attention_mask=k_mask, normalize=self.norm_doc)
+        q = self.encoder_q(input_ids=q_tokens, attention_mask=q_mask, normalize=self.norm_query)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            k.record_stream(torch.cuda.current_stream())
+
         with torch.no_grad():
-            self._momentum_update_key_encoder()
-            if not self.encoder_k.training and not self.moco_train_mode_encoder_k:
-                self.encoder_k.eval()
-            if kx is not None:
+            if side is None:
+                self._momentum_update_key_encoder()
+                if not self.encoder_k.training and not self.moco_train_mode_encoder_k:
+                    self.encoder_k.eval()
+            if side is not None:
+                pass
+            elif kx is not None:
                 # cross-GPU negatives: the first half of the keys is on its way to the other ranks while the key encoder
                 # finishes the second half; the second half travels under the InfoNCE head below (KeyExchange)
                 n_first = kx.split_for(bsz, k_tokens.size(1)) if self.key_gather_split else 0

@@ -467,3 +467,44 @@ def test_dropout_backward_never_reads_unwritten_workspace(gpu, B, S, lengths):
     assert torch.equal(g0[:nm], g1[:nm])                                   # split-K weight gradients: fixed summation order
     scale = float(g0[nm:].abs().max()) + 1e-12
     assert float((g0[nm:] - g1[nm:]).abs().max()) <= 1e-5 * scale          # fp32 atomics: order-dependent last bits only
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_key_encoder_on_second_stream_changes_nothing(gpu, tmp_path, dropout):
+    """MoCo.key_overlap: EMA + key-encoder forward on a second HIP stream beside the query encoder's forward (one GPU).
+    Same kernels on the same inputs, only their interleaving differs: loss trace, queue, pointer and key-encoder weights
+    bit-identical at step 0, everything equal to the float atomics' rounding afterwards."""
+    from src import moco, utils
+    mdir = _write_cfg(tmp_path / "tiny", TINY, hidden_dropout_prob=dropout, attention_probs_dropout_prob=dropout)
+    res = []
+    for overlap in (False, True):
+        torch.manual_seed(0)
+        opt = _moco_opt(mdir, norm_query=True, norm_doc=True)
+        model = moco.MoCo(opt)
+        P = O.make_params(O.BertShape(**TINY), 71)
+        model.encoder_q.load_state_dict(P)
+        model.encoder_k.load_state_dict(P)
+        model = model.cuda().train()
+        model.key_overlap = overlap
+        optimizer, scheduler = utils.set_optim(opt, model)
+        losses, queue0 = [], None
+        for step in range(4):
+            qt, qm = ragged_batch(8, 24, 7300 + step, 512, [24, 17, 3, 24, 9, 24, 12, 20])
+            kt, km = ragged_batch(8, 24, 7400 + step, 512, [20, 24, 5, 11, 24, 7, 24, 16])
+            loss, _ = model(qt.to(gpu), qm.to(gpu), kt.to(gpu), km.to(gpu), stats_prefix="train")
+            loss.backward()
+            optimizer.step(); scheduler.step(); model.zero_grad()
+            losses.append(float(loss.detach()))
+            if step == 0:
+                queue0 = model.queue.clone()
+        torch.cuda.synchronize()
+        assert (model._key_stream is not None) == overlap
+        res.append((losses, queue0.cpu(), model.queue.cpu(), int(model.queue_ptr), model.encoder_q.flat_params.cpu(),
+                    model.encoder_k.flat_params.cpu()))
+    (l0, q00, qa, pa, wqa, wka), (l1, q01, qb, pb, wqb, wkb) = res
+    assert l0[0] == l1[0] and torch.equal(q00, q01) and pa == pb == 32
+    assert max(abs(a - b) for a, b in zip(l0, l1)) < 2e-3
+    assert float((qa - qb).abs().max()) < 1e-3
+    for a, b in ((wqa, wqb), (wka, wkb)):
+        d = (a - b).abs()
+        assert float(d.max()) < 2.5e-3 and float(d.mean()) < 2e-5, (float(d.max()), float(d.mean()))
