@@ -863,398 +863,6 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   }  // tile loop
 }
 
-// ---- wave-specialised kernel ---------------------------------------------------------------------
-// K-major x K-major products with a SHORT reduction (K = 768: QKV, attention output, FFN-up forward and the FFN-down
-// input gradient through the transposed weight mirror) whose shapes tile exactly: M % 256 == 0, N % 128 == 0, K % 192
-// == 0, K >= 768.  With 12 K-tiles per output tile the 256 x 256 kernel spends a fifth to a third of a tile outside its
-// K-loop (epilogue arithmetic and stores that nothing overlaps: one workgroup per CU, every register an accumulator or a
-// fragment; the store phase alone is bound per CU at ~40-70 cycles per 1-KiB store instruction).  Here a 512-thread
-// workgroup per CU walks over 256 x 128 output tiles and its waves have two ROLES, one wave of each per SIMD (waves w
-// and w + 4 share a SIMD):
-//   consumers (waves 0-3, 2 x 2, 128 x 64 outputs each): fragment reads and MFMAs, ONE barrier per K-tile, sitting in the
-//     middle of the MFMA stream (the next K-tile's first fragments are requested right behind it, under the 16 MFMAs of
-//     this K-tile's last phase).  The bias rides in as the C operand of each accumulator's first MFMA.  They never touch
-//     global memory for the output: at a tile's end the accumulators are rounded to bf16 into LDS (below) and the next
-//     tile's K-loop goes on with fragments that are already in flight.
-//   helpers (waves 4-7): every LDS-DMA request of the K-loop (12 pieces per K-tile and wave, ~100 issue cycles each: a
-//     wave that also feeds the matrix pipe cannot afford them) two K-tiles ahead of the consumers through a ring of
-//     three stages, and the whole epilogue of the PREVIOUS tile under the current tile's K-loop: two sets of 16-byte
-//     row pieces per K-tile, from REGISTERS -- bias is in already; GELU and its derivative, x stored derivative with
-//     column sums, + residual gradient (second operand by LDS DMA into the idle slices, one K-tile ahead) -- and the
-//     stores, 1-4 per K-tile instead of a burst.
-// The hand-over: K-tiles form one stream over all the tiles of a workgroup, K-tile g in ring stage g % 3, every tile
-// starting in stage 0.  After a tile's last barrier stage 2 is free (it held the tile's last K-tile) and the refill due
-// there is two K-tiles away, so stage 2 plus the four 4-KiB slices behind it are one contiguous 64 KiB window: the
-// consumers dump the tile there (barrier), each helper pulls its consumer's 128 x 64 region into 64 registers while
-// the consumers multiply the next tile's first two phases (barrier), and the DMA stream goes on into stage 2.
-// Barriers (same sequence in both roles): prologue; per tile [pull, from the second tile on], one per K-tile, dump.
-// At the barrier of K-tile g the helpers have waited for the DMA of K-tile g + 1 (counted vmcnt: K-tile g + 2 stays in
-// flight) and every consumer has finished reading K-tile g, whose stage the helpers refill next.
-// LDS: 3 stages x (A 32 KiB + B 16 KiB) + 4 x 4 KiB slices = 160 KiB.
-constexpr int WS_BM = 256, WS_BN = 128, WS_NSTG = 3;
-constexpr int WS_TILE_A = WS_BM * BK * 2, WS_TILE_B = WS_BN * BK * 2, WS_STAGE = WS_TILE_A + WS_TILE_B;
-constexpr int WS_WIN = 2 * WS_STAGE;             // the dump window: stage 2 + the slices
-constexpr int WS_SLICE = WS_NSTG * WS_STAGE, WS_LDS = WS_SLICE + 4 * 4096;
-static_assert(WS_LDS - WS_WIN == WS_BM * WS_BN * 2, "stage 2 + slices hold exactly one bf16 tile");
-
-#define CZC_WS_BAR() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
-
-// TIMING: tools/bench_gemm.py only -- the K-loop alone, nothing handed over or stored
-template <int EPI, bool TIMING = false>
-__global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const GemmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nt = a.K / BK;                     // K-tiles per output tile: a multiple of 3, >= 12 (host)
-  const int ntiles = a.tiles_m * a.tiles_n;
-  constexpr bool HAS_BIAS = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU1);
-  constexpr bool AUX = (EPI == EPI_DGELU || EPI == EPI_ADD);
-  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-
-  if (wave < 4) {
-    // ------------------------------------------------ consumer ------------------------------------------------
-    const int wm = wave >> 1, wn = wave & 1;
-    f32x4 acc[8][4];
-    // fragments: the two k-steps' B operands, and two half-sets of A (rows lo / hi of the wave's 128) that alternate:
-    // while one half is multiplied the next half's reads are in flight (4 or 8 ds_read_b128 under 16 MFMAs)
-    bf16x8 faA[4], faB[4], fb0[4], fb1[4];
-    // Fragment addresses = one of eight lane registers + an immediate: lane part L(ks) = (lane & 15) * 128 + 16 * ((4 ks +
-    // lane / 16) ^ ((lane & 15) / 2 & 7)) (the K-major image's swizzle, frag_kmajor), plus the wave's row / column block;
-    // ring stages 0 and 1 are reached by the instruction's 16-bit offset, stage 2 (98 304 B on) has registers of its own.
-    int a_k0, a_k1, b_k0, b_k1, a2_k0, a2_k1, b2_k0, b2_k1;
-    {
-      const int l15 = lane & 15, sw = (l15 >> 1) & 7, hi = lane >> 4;
-      const int L0 = l15 * 128 + ((hi ^ sw) << 4), L1 = l15 * 128 + (((4 + hi) ^ sw) << 4);
-      a_k0 = L0 + wm * 16384; a_k1 = L1 + wm * 16384;
-      b_k0 = L0 + WS_TILE_A + wn * 8192; b_k1 = L1 + WS_TILE_A + wn * 8192;
-      a2_k0 = a_k0 + 2 * WS_STAGE; a2_k1 = a_k1 + 2 * WS_STAGE; b2_k0 = b_k0 + 2 * WS_STAGE; b2_k1 = b_k1 + 2 * WS_STAGE;
-      asm volatile("" : "+v"(a_k0), "+v"(a_k1), "+v"(b_k0), "+v"(b_k1), "+v"(a2_k0), "+v"(a2_k1), "+v"(b2_k0), "+v"(b2_k1));
-    }
-    auto rd_a = [&](bf16x8 (&fa)[4], int ks, int half, int stage) {
-      const int base = stage == 2 ? (ks ? a2_k1 : a2_k0) : (ks ? a_k1 : a_k0);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = *(const bf16x8*)(smem + base + (stage == 1 ? WS_STAGE : 0) + (4 * half + i) * 2048);
-    };
-    auto rd_b = [&](bf16x8 (&fb)[4], int ks, int stage) {
-      const int base = stage == 2 ? (ks ? b2_k1 : b2_k0) : (ks ? b_k1 : b_k0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8*)(smem + base + (stage == 1 ? WS_STAGE : 0) + j * 2048);
-    };
-    // the phase's NR reads go out one per MFMA from its start: the last of them has 16 - NR MFMAs to come back before
-    // the next phase wants it
-#define CZC_WS_SCHED(NR)                                                         \
-    _Pragma("unroll") for (int q_ = 0; q_ < (NR); ++q_) {                        \
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                         \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                         \
-    }                                                                            \
-    __builtin_amdgcn_sched_group_barrier(0x008, 16 - (NR), 0);
-#define CZC_WS_MFMA(FA, FB, HALF)                                                \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                \
-      acc[4 * (HALF) + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j], FA[i], acc[4 * (HALF) + i][j], 0, 0, 0);
-#define CZC_WS_MFMA_FIRST(FA, FB, HALF)                                          \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                \
-      acc[4 * (HALF) + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j], FA[i], bv[j], 0, 0, 0);
-    // K-tile in stage ST; on entry faA = A(lo, k-step 0) and fb0 = B(k-step 0) of it, on exit those of the next K-tile.
-    // PULL (a tile's first K-tile, from the second tile on): the barrier behind which the helpers have emptied the window
-#define CZC_WS_KTILE(ST, FIRST, PULL)                                            \
-    {                                                                            \
-      rd_a(faB, 0, 1, ST);                                                       \
-      if (FIRST) { CZC_WS_MFMA_FIRST(faA, fb0, 0) } else { CZC_WS_MFMA(faA, fb0, 0) } \
-      CZC_WS_SCHED(4)                                                            \
-      rd_b(fb1, 1, ST);                                                          \
-      rd_a(faA, 1, 0, ST);                                                       \
-      if (FIRST) { CZC_WS_MFMA_FIRST(faB, fb0, 1) } else { CZC_WS_MFMA(faB, fb0, 1) } \
-      CZC_WS_SCHED(8)                                                            \
-      if (PULL) { __builtin_amdgcn_sched_barrier(0); CZC_WS_BAR(); __builtin_amdgcn_sched_barrier(0); } \
-      rd_a(faB, 1, 1, ST);                                                       \
-      CZC_WS_MFMA(faA, fb1, 0)                                                   \
-      CZC_WS_SCHED(4)                                                            \
-      __builtin_amdgcn_sched_barrier(0);                                         \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         \
-      CZC_WS_BAR();                                                              \
-      __builtin_amdgcn_sched_barrier(0);                                         \
-      rd_b(fb0, 0, ((ST) + 1) % WS_NSTG);                                        \
-      rd_a(faA, 0, 0, ((ST) + 1) % WS_NSTG);                                     \
-      CZC_WS_MFMA(faB, fb1, 1)                                                   \
-      CZC_WS_SCHED(8)                                                            \
-      __builtin_amdgcn_sched_barrier(0);                                         \
-    }
-    __builtin_amdgcn_s_setprio(1);
-    unsigned char* win = smem + WS_WIN + wave * (128 * 128);   // this wave's 128 x 64 region of the dump window
-    CZC_WS_BAR();                                  // prologue: K-tile 0 of the first tile has landed
-    rd_b(fb0, 0, 0);
-    rd_a(faA, 0, 0, 0);
-    bool have_prev = false;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-      f32x4 bv[4];
-      {
-        int tm, tn;
-        swizzle_tile(tile, ntiles, a.tiles_m, a.tiles_n, a.group_n, tm, tn);
-        int lt = tid;
-        asm volatile("" : "+v"(lt));   // lane-derived addresses of the seams are made HERE, not hoisted over the K-loops
-        const int nq_ = (lt & 63) >> 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          bv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (HAS_BIAS) bv[j] = *(const f32x4*)(a.bias + tn * WS_BN + wn * 64 + 16 * j + 4 * nq_);
-        }
-      }
-      if (have_prev && !TIMING) { CZC_WS_KTILE(0, true, true) } else { CZC_WS_KTILE(0, true, false) }
-      CZC_WS_KTILE(1, false, false)
-      CZC_WS_KTILE(2, false, false)
-      for (int kt = 3; kt < nt; kt += 3) {
-        CZC_WS_KTILE(0, false, false)
-        CZC_WS_KTILE(1, false, false)
-        CZC_WS_KTILE(2, false, false)
-      }
-      have_prev = true;
-      if (TIMING) {
-        _Pragma("unroll") for (int i = 0; i < 8; ++i)
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));   // keep the products alive
-        continue;
-      }
-      // the tile leaves: bf16 into this wave's region of the window (128 rows x 128 B, 16-B chunks XOR-swizzled by row & 7)
-      {
-        int lt = tid;
-        asm volatile("" : "+v"(lt));
-        const int mrow_ = lt & 15, nq_ = (lt & 63) >> 4;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int rl = 16 * i + mrow_;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            uint2 w;
-            w.x = pack2bf(acc[i][j][0], acc[i][j][1]);
-            w.y = pack2bf(acc[i][j][2], acc[i][j][3]);
-            const int chunk = (2 * j + (nq_ >> 1)) ^ (rl & 7);
-            *(uint2*)(win + rl * 128 + chunk * 16 + (nq_ & 1) * 8) = w;
-          }
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      CZC_WS_BAR();                                // dump: the window holds the tile
-    }
-#undef CZC_WS_KTILE
-#undef CZC_WS_MFMA
-#undef CZC_WS_MFMA_FIRST
-#undef CZC_WS_SCHED
-    return;
-  }
-
-  // -------------------------------------------------- helper --------------------------------------------------
-  const int h = wave - 4;
-  unsigned poff_a[8], poff_b[4];
-  auto set_tile = [&](int tile, int& r0, int& c0) {
-    int tm, tn;
-    swizzle_tile(tile, ntiles, a.tiles_m, a.tiles_n, a.group_n, tm, tn);
-    r0 = tm * WS_BM; c0 = tn * WS_BN;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) poff_a[i] = piece_off_kmajor_q(a.lda, r0, 8 * h + i, lane);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) poff_b[i] = piece_off_kmajor_q(a.ldb, c0, 4 * h + i, lane);
-  };
-  // part 0 / 1: the first / second six of this wave's twelve pieces of a K-tile; part 2: all twelve
-  auto dma = [&](int kt, int stage, int part = 2) {
-    const char* ba = (const char*)a.A + (size_t)kt * (BK * 2);
-    const char* bb = (const char*)a.B + (size_t)kt * (BK * 2);
-    unsigned char* ta = smem + stage * WS_STAGE;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (part == 2 || (i >> 2) == part) glds16(ba + poff_a[i], (lptr_t)(ta + (8 * h + i) * 1024));
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (part == 2 || (i >> 1) == part) glds16(bb + poff_b[i], (lptr_t)(ta + WS_TILE_A + (4 * h + i) * 1024));
-  };
-  // ---- the previous tile's epilogue.  Helper h owns the 128 x 64 region consumer h dumped: 16 sets of 64 lanes x 16 B
-  // (set `it`: rows 8 it .. 8 it + 7), pulled into T[it].  The second operand of set `it` (AUX) comes by ONE LDS-DMA piece
-  // into this helper's slice (piece it & 1) a K-tile before the set is worked on.
-  const unsigned cbytes = (unsigned)min((size_t)a.M * (size_t)a.ldc * 2u, (size_t)0xfffffff0u);
-  __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, cbytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rc2 = __builtin_amdgcn_make_buffer_rsrc(EPI == EPI_BIAS_GELU ? a.C2 : a.C, 0, cbytes, 0x00020000);
-  unsigned char* slice = smem + WS_SLICE + h * 4096;
-  u32x4 T[16];
-  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // DGELU: this lane's 8 columns over the rows it has seen of the tile
-  auto pull = [&]() {
-    const unsigned char* reg = smem + WS_WIN + h * (128 * 128);
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int idx = it * 64 + lane, rl = idx >> 3, ch = idx & 7;
-      T[it] = *(const u32x4*)(reg + rl * 128 + ((ch ^ (rl & 7)) << 4));
-    }
-  };
-  auto seg_off = [&](int it, int er0, int ec0) -> size_t {     // byte offset of this lane's 16 B of set `it`
-    const int idx = it * 64 + lane, rl = idx >> 3, ch = idx & 7;
-    return ((size_t)(er0 + (h >> 1) * 128 + rl) * a.ldc + ec0 + (h & 1) * 64 + ch * 8) * 2u;
-  };
-  auto fetch_aux = [&](int it, int er0, int ec0) {
-    if (AUX) glds16((const char*)a.aux + seg_off(it, er0, ec0), (lptr_t)(slice + (it & 1) * 1024));
-  };
-  auto process = [&](const u32x4 v, int it, int er0, int ec0) {
-    const unsigned off = (unsigned)seg_off(it, er0, ec0);
-    if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU1) {
-      float xin[8], gl[8], dg[8];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { xin[2 * e] = bflo(v[e]); xin[2 * e + 1] = bfhi(v[e]); }
-      if (EPI == EPI_BIAS_GELU) gelu8<2>(xin, gl, dg);
-      else gelu8<0>(xin, gl, dg);
-      u32x4 g;
-      if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) g[e] = pack2bf(dg[2 * e], dg[2 * e + 1]);
-        store16(g, rc, off, a.store_pol);
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] = pack2bf(gl[2 * e], gl[2 * e + 1]);
-      store16(g, rc2, off, a.store_pol);
-    } else if (AUX) {
-      const u32x4 u = *(const u32x4*)(slice + (it & 1) * 1024 + lane * 16);
-      u32x4 g;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float lo, hi;
-        if (EPI == EPI_DGELU) { lo = bflo(v[e]) * bflo(u[e]); hi = bfhi(v[e]) * bfhi(u[e]); csum[2 * e] += lo; csum[2 * e + 1] += hi; }
-        else { lo = bflo(v[e]) + bflo(u[e]); hi = bfhi(v[e]) + bfhi(u[e]); }
-        g[e] = pack2bf(lo, hi);
-      }
-      store16(g, rc, off, a.store_pol);
-    } else {
-      store16(v, rc, off, a.store_pol);
-    }
-  };
-  // DGELU: fold the tile's column sums (lanes with equal lane & 7 own the same 8 columns) into one partial row per
-  // (256-row tile, wave row): colsum[(tm * 2 + wm)][N], written whole -- the layout the 256 x 256 kernel writes
-  auto flush_csum = [&](int er0, int ec0) {
-    if (EPI != EPI_DGELU) return;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float t = csum[j];
-      t += dpp_mov<0x128>(t);
-      csum[j] = xor32_sum(xor16_sum(t));
-    }
-    if (a.colsum && (lane >> 3) == 0) {
-      float* row = a.colsum + (size_t)((er0 / WS_BM) * 2 + (h >> 1)) * a.N + ec0 + (h & 1) * 64 + (lane & 7) * 8;
-      *(f32x4*)row = (f32x4){csum[0], csum[1], csum[2], csum[3]};
-      *(f32x4*)(row + 4) = (f32x4){csum[4], csum[5], csum[6], csum[7]};
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) csum[j] = 0.f;
-  };
-  int dr0, dc0;                                      // the tile the DMA stream is in (poff_* belong to it)
-  int dma_tile = blockIdx.x, dma_kt = 2, dstage = 2;
-  set_tile(dma_tile, dr0, dc0);
-  dma(0, 0);
-  dma(1, 1);
-  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  CZC_WS_BAR();                                      // prologue
-  int cr0 = dr0, cc0 = dc0, pr0 = 0, pc0 = 0;        // current / previous tile
-  bool have_prev = false, deferred = false;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    for (int kt = 0; kt < nt; ++kt) {
-      const bool pulling = (kt == 0 && have_prev && !TIMING);
-      if (pulling) {
-        pull();                                      // the previous tile: out of the window, into registers
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        CZC_WS_BAR();                                // pull: the window (stage 2, the slices) is free again
-      }
-      if (kt == 1 && deferred) { dma(2, 2, 1); deferred = false; }   // the second half of the request the pull held back
-      // request K-tile g + 2 of the stream into the stage the last barrier freed (at kt == 0: stage 2, the window)
-      if (dma_kt == nt) {
-        dma_tile += gridDim.x;
-        dma_kt = 0;
-        if (dma_tile < ntiles) set_tile(dma_tile, dr0, dc0);
-      }
-      bool issued = false;
-      if (dma_tile < ntiles) {
-        // behind a pull only half of the request goes out before this K-tile's barrier (the consumers are waiting at
-        // it: a dozen pieces cost ~1 k cycles of issue), the rest right behind it: K-tile 2 is not read before barrier 1
-        if (pulling) { dma(dma_kt, dstage, 0); deferred = true; }
-        else dma(dma_kt, dstage);
-        ++dma_kt;
-        issued = true;
-      }
-      dstage = (dstage + 1 == WS_NSTG) ? 0 : dstage + 1;
-      // K-tile g + 1 has landed (what was requested in THIS iteration stays in flight), and so have the second operands
-      // fetched one K-tile ago
-      if (!issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (pulling) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      if (have_prev && !TIMING) {
-        // the 16 sets from registers (static indices: a switch) over K-tiles 1 .. 11: two per K-tile, then one; the
-        // second operands of a K-tile's sets are fetched one K-tile ahead
-#define CZC_WS_SET2(KT, S)                                                       \
-        case KT:                                                                 \
-          process(T[S], S, pr0, pc0);                                            \
-          process(T[(S) + 1], (S) + 1, pr0, pc0);                                \
-          if ((S) + 2 < 10) { fetch_aux((S) + 2, pr0, pc0); fetch_aux((S) + 3, pr0, pc0); } \
-          else fetch_aux((S) + 2, pr0, pc0);                                     \
-          break;
-#define CZC_WS_SET1(KT, S)                                                       \
-        case KT:                                                                 \
-          process(T[S], S, pr0, pc0);                                            \
-          if ((S) + 1 < 16) fetch_aux((S) + 1, pr0, pc0);                        \
-          else flush_csum(pr0, pc0);                                             \
-          break;
-        switch (kt) {
-          case 0: fetch_aux(0, pr0, pc0); fetch_aux(1, pr0, pc0); break;
-          CZC_WS_SET2(1, 0) CZC_WS_SET2(2, 2) CZC_WS_SET2(3, 4) CZC_WS_SET2(4, 6) CZC_WS_SET2(5, 8)
-          CZC_WS_SET1(6, 10) CZC_WS_SET1(7, 11) CZC_WS_SET1(8, 12) CZC_WS_SET1(9, 13) CZC_WS_SET1(10, 14) CZC_WS_SET1(11, 15)
-          default: break;
-        }
-      }
-      CZC_WS_BAR();
-    }
-    pr0 = cr0; pc0 = cc0; have_prev = true;
-    cr0 = dr0; cc0 = dc0;                              // the DMA stream moved on to the next tile during the last K-tiles
-    CZC_WS_BAR();                                      // dump: the consumers have put this tile into the window
-  }
-  if (!TIMING) {                                       // the last tile: nothing left to overlap it with
-    pull();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      if (AUX) { fetch_aux(it, pr0, pc0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-      process(T[it], it, pr0, pc0);
-    }
-    flush_csum(pr0, pc0);
-  }
-#undef CZC_WS_SET1
-#undef CZC_WS_SET2
-}
-
-static int g_store_pol = -1;   // -1 = built-in choice; czc_gemm_set_tile +512: sc1 output stores, +1024: nt, +2048: plain
-template <int EPI, bool TIMING = false>
-static int launch_ws(GemmArgs a, hipStream_t st) {
-  static bool attr_done = false;
-  auto kern = gemm_ws_kernel<EPI, TIMING>;
-  if (!attr_done) {
-    CZC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS));
-    attr_done = true;
-  }
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    CZC_HIP(hipGetDevice(&dev));
-    CZC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  }
-  a.tiles_m = a.M / WS_BM;
-  a.tiles_n = a.N / WS_BN;
-  a.store_pol = g_store_pol >= 0 ? g_store_pol : 2;   // streaming stores (plain ones cost this kernel 20-25 %: its K-loop lives on L2 hits)
-  a.group_n = (a.tiles_n >= 24) ? 12 : a.tiles_n;    // the same 6 x 256 columns of B per sweep as the 256 x 256 kernel
-  const int ntiles = a.tiles_m * a.tiles_n;
-  hipLaunchKernelGGL(kern, dim3(min(ntiles, cus)), dim3(512), WS_LDS, st, a);
-  CZC_LAUNCH_CHECK();
-  return CZC_OK;
-}
-static int g_ws = 0;   // 0 = built-in choice; czc_gemm_set_tile: +128 = wherever the shape allows, +256 = never
-static bool ws_eligible(const GemmArgs& a, int splits) {
-  const size_t ea = (size_t)a.M * a.lda, eb = (size_t)a.N * a.ldb;
-  return splits == 1 && a.M % WS_BM == 0 && a.N % WS_BN == 0 && a.K % (3 * BK) == 0 && a.K >= 12 * BK &&
-         ea * 2 < (1ull << 31) && eb * 2 < (1ull << 31) && (size_t)a.M * a.ldc * 2 < (1ull << 32) && a.cfg == 0;
-}
-
 // ---- host launcher ---------------------------------------------------------------------------
 typedef Cfg<2, 4, 8> CfgBig;
 typedef Cfg<2, 2, 4> CfgSmall;
@@ -1262,6 +870,7 @@ static int g_tile_override = 0;  // 0 = heuristic, 1 = 256x256, 2 = 128x128
 static bool g_one_wg_per_tile = false;
 static int g_pingpong = 0;             // 0 = built-in choice; tuning knob czc_gemm_set_tile: +32 = always, +64 = never  // tuning knob: switch the persistent tile loop off
 
+static int g_store_pol = -1;   // -1 = built-in choice; czc_gemm_set_tile +512: sc1 output stores, +1024: nt, +2048: plain
 template <int AL, int BL, int EPI, class CF, bool PP = false>
 static int launch_cfg(GemmArgs a, int splits, hipStream_t st) {
   static bool attr_done = false;
@@ -1306,17 +915,6 @@ static int launch_cfg(GemmArgs a, int splits, hipStream_t st) {
 
 template <int AL, int BL, int EPI>
 static int launch(const GemmArgs& a, int splits, hipStream_t st) {
-  if constexpr (AL == 0 && BL == 0 && (EPI == EPI_STORE || EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU1 ||
-                                       EPI == EPI_DGELU || EPI == EPI_ADD)) {
-    // built-in choice: the plain epilogues at K <= 1024 (measured, interleaved A/B at 65536 rows, nt stores on both sides:
-    // QKV 215 -> 201 us, attention output 75 -> 68, its input gradient 74 -> 66); the epilogues the helpers must compute
-    // (GELU forms, x stored derivative, + residual) make the helpers the pacing role and lose 5-15 %, long reductions lose
-    // to the 256 x 256 tile's operand reuse (K = 3072: 246 -> 285 us)
-    constexpr bool PLAIN = (EPI == EPI_STORE || EPI == EPI_BIAS);
-    // (not beside a collective -- czc_gemm_set_tile +16 --: its launch is sized to all the CUs)
-    if ((g_ws == 1 || (g_ws == 0 && PLAIN && a.K <= 1024 && !g_one_wg_per_tile)) && ws_eligible(a, splits)) return launch_ws<EPI>(a, st);
-    if (EPI == EPI_STORE && g_ws == 3 && ws_eligible(a, splits)) return launch_ws<EPI_STORE, true>(a, st);   // timing build
-  }
   int cfg = a.cfg ? a.cfg : g_tile_override;
   if (EPI == EPI_LSE || EPI == EPI_SOFTGRAD || a.colsum) cfg = 1;  // partial-sum rows are laid out for 256-row tiles
   if (cfg == 0) cfg = (ceil_div(a.M, 256) * ceil_div(a.N, 256) * splits < 128 && !a.colsum) ? 2 : 1;
@@ -1441,14 +1039,12 @@ extern "C" int czc_gemm_bf16(int a_layout, int b_layout, int epilogue, int M, in
 extern "C" int czc_gemm_set_tile(int cfg) {
   g_store_pol = (cfg & 512) ? 1 : (cfg & 1024) ? 2 : (cfg & 2048) ? 0 : -1;
   cfg &= ~3584;
-  CZC_REQUIRE((cfg & ~496) >= 0 && (cfg & ~496) <= 2,
+  CZC_REQUIRE((cfg & ~112) >= 0 && (cfg & ~112) <= 2,
               "czc_gemm_set_tile: cfg=%d (0 default, 1 = 256x256, 2 = 128x128; +16 = one workgroup per tile; "
-              "+32 / +64 = ping-pong K-loop always / never; +128 / +256 = wave-specialised kernel wherever possible / never; "
-              "+512 / +1024 / +2048 = sc1 / nt / plain output stores)", cfg);
-  g_tile_override = cfg & ~496;
+              "+32 / +64 = ping-pong K-loop always / never; +512 / +1024 / +2048 = sc1 / nt / plain output stores)", cfg);
+  g_tile_override = cfg & ~112;
   g_one_wg_per_tile = (cfg & 16) != 0;
   g_pingpong = (cfg & 32) ? 1 : ((cfg & 64) ? 2 : 0);
-  g_ws = ((cfg & 384) == 384) ? 3 : (cfg & 128) ? 1 : ((cfg & 256) ? 2 : 0);   // both bits: the three-stage timing build (STORE only, stores nothing)
   return CZC_OK;
 }
 

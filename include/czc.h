@@ -222,10 +222,8 @@ int czc_gemm_bf16(int a_layout, int b_layout, int epilogue, int M, int N, int K,
  * + 16 = one workgroup per output tile instead of workgroups that walk over several tiles (tuning A/B; launches beside
  *        a collective);
  * + 32 / + 64 = the ping-pong K-loop always / never (default: chosen per shape);
- * + 128 / + 256 = the wave-specialised 256x128 kernel (consumer waves: MFMA stream; helper waves: LDS DMA and the previous
- *        tile's epilogue) wherever the shape allows / never (default: the store / bias epilogues of K-major products with
- *        768 <= K <= 1024, M % 256 == 0, N % 128 == 0, K % 192 == 0); both bits: its K-loop alone, nothing stored (timing);
- * + 512 / + 1024 / + 2048 = sc1 / nt / plain bf16 output stores (default: nt for N >= 2048 and in the wave-specialised kernel) */
+ * + 512 / + 1024 / + 2048 = sc1 / nt / plain bf16 output stores (default: nt, streaming, for N >= 2048: a wide tile's
+ *        128 KiB per CU otherwise competes with the operand panels for the XCD's L2) */
 int czc_gemm_set_tile(int cfg);
 /* Timing probe (bench only): records hipEvents on the launch stream around every czc GEMM launch whose
  * (layouts, epilogue, M, N, K) match, up to max_samples launches; max_samples <= 0 disarms.

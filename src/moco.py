@@ -112,7 +112,8 @@ class MoCo(nn.Module):
         self.key_gather_split = True   # data parallel: last key-encoder layer in two halves, first half's all-gather under it
         # one GPU: the key encoder's pass (EMA + forward, nothing differentiates through it) is independent of the query
         # encoder's forward; on a second HIP stream the two passes' kernels fill each other's launch gaps and tails
-        self.key_overlap = os.environ.get("CZC_KEY_OVERLAP", "0") == "1"
+        # (interleaved A/B at the headline shapes: 55.79 -> 55.63 ms per step; CZC_KEY_OVERLAP=0 switches it off)
+        self.key_overlap = os.environ.get("CZC_KEY_OVERLAP", "1") == "1"
         self._key_stream = None
 
         retriever, tokenizer = self._load_retriever(opt.retriever_model_id, pooling=opt.pooling,

@@ -591,42 +591,3 @@ def test_infonce_saturated_positive_is_exactly_zero(ops):
         assert float(stats[0]) == 0.0, float(stats[0])
         assert float(dq.abs().max()) == 0.0, float(dq.abs().max())
         assert float(stats[1]) == 100.0
-
-
-@pytest.mark.parametrize("M,N,K", [(512, 256, 1152), (1024, 384, 768), (2048, 768, 3072), (66 * 256, 128, 384),
-                                   (67 * 256, 256, 768)])
-def test_gemm_wave_specialised_kernel(ops, M, N, K):
-    """The wave-specialised kernel (consumer waves: MFMA stream; helper waves: LDS DMA + the previous tile's epilogue under
-    the next tile's K-loop; czc_gemm_set_tile +128) against the 256 x 256 kernel (+256) and the fp32 reference, for every
-    bf16 epilogue it takes over, with fewer tiles than CUs, as many, and more (workgroups walking over several tiles)."""
-    from czech_contriever_amd import lib as L
-    a, b, A, Bm = _mk(M, N, K, 0, 0, 91)
-    bias = rnd(N, seed=92)
-    aux = rnd(M, N, seed=93, dtype=BF16)
-    acc = a.float() @ b.float().t()
-    lib = L.load()
-    cases = [("store", {}), ("bias", dict(bias=bias)), ("add", dict(aux=aux)), ("dgelu", dict(aux=aux)),
-             ("bias_gelu", dict(bias=bias)), ("bias_gelu_only", dict(bias=bias))]
-    for epi, kw in cases:
-        outs = []
-        for cfg in (257, 129):
-            L.check(lib.czc_gemm_set_tile(cfg))
-            try:
-                o = ops.gemm(A, Bm, epilogue=epi, **kw)
-            finally:
-                L.check(lib.czc_gemm_set_tile(0))
-            outs.append(o)
-        base, ws = outs
-        if epi in ("store", "add", "dgelu"):       # same MFMA chain per element, same roundings: bit for bit
-            assert torch.equal(base, ws), (epi, (base.float() - ws.float()).abs().max())
-        elif epi == "bias":                        # the bias enters as the first MFMA's C operand instead of last
-            report("ws bias", ws, acc + bias, 5e-2, 8e-3)
-            assert bool(((base.float() - ws.float()).abs() <= 2.0 ** -7 * base.float().abs() + 1e-3).all())   # one bf16 ulp
-        elif epi == "bias_gelu":
-            u = (acc + bias).to(BF16).float().requires_grad_(True)
-            ref_h = torch.nn.functional.gelu(u)
-            ref_h.sum().backward()
-            report("ws gelu(u)", ws[1], ref_h.detach(), 2e-2, 8e-3)
-            report("ws gelu'(u)", ws[0], u.grad, 2e-2, 8e-3)
-        else:
-            report("ws gelu only", ws, torch.nn.functional.gelu(acc + bias), 2e-2, 8e-3)

@@ -30,16 +30,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "pp":
     variants = [("plain", 65, 0), ("pingpong", 33, 0), ("auto", 1, 0)]
 if len(sys.argv) > 1 and sys.argv[1] == "persist":
     variants = [("persist", 1, 0), ("per-tile", 17, 0)]
-if len(sys.argv) > 1 and sys.argv[1] == "ws":
-    variants = [("base", 257 + 2048, 0), ("base-nt", 257 + 1024, 0), ("ws", 129 + 2048, 0), ("ws-nt", 129 + 1024, 0), ("kloop", 385, 0), ("default", 0, 0)]
-    WT = {"w2t": r(I, H), "w1t": r(H, I), "ot": r(H, H), "qkvt": r(H, 3 * H)}   # transposed mirrors: K-major B operands of the dX products
-    cases = [("store M,2304,768", lambda: ops.gemm(X, W["qkv"]), 2 * M * 2304 * 768),
-             ("store M,3072,768", lambda: ops.gemm(X, W["w1"]), 2 * M * 3072 * 768)] + cases[:4] + [
-        ("fwd ffn1k bias_gelu_only M,3072,768", lambda: ops.gemm(X, W["w1"], epilogue="bias_gelu_only", bias=bias["w1"]), 2 * M * 3072 * 768),
-        ("bwd dH  T dgelu     M,3072,768", lambda: ops.gemm(YH, WT["w2t"], epilogue="dgelu", aux=YI), 2 * M * 3072 * 768),
-        ("bwd dX1 T add       M,768,3072", lambda: ops.gemm(YI, WT["w1t"], epilogue="add", aux=YH), 2 * M * 768 * 3072),
-        ("bwd dctxT store     M,768,768", lambda: ops.gemm(YH, WT["ot"]), 2 * M * 768 * 768),
-        ("bwd dXinT add       M,768,2304", lambda: ops.gemm(Y3, WT["qkvt"], epilogue="add", aux=YH), 2 * M * 768 * 2304)]
+if len(sys.argv) > 1 and sys.argv[1] == "stores":
+    variants = [("plain", 1 + 2048, 0), ("nt", 1 + 1024, 0), ("sc1", 1 + 512, 0)]
 if len(sys.argv) > 1 and sys.argv[1] == "tiles":
     variants = [("tile256", 1, 0), ("tile128", 2, 0)]
 def timeit(fn, n=8):

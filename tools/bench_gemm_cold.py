@@ -1,6 +1,8 @@
 """Dev tool: the QKV / attention-output products with operands and outputs that rotate over buffers far larger than the
 256 MiB Infinity Cache (what a layer sees inside the training step: its input was written by another kernel, its output
-goes to fresh memory), 256 x 256 kernel against the wave-specialised one, interleaved in ONE process."""
+goes to fresh memory), GEMM settings interleaved in ONE process.  A back-to-back loop over the same buffers (tools/
+bench_gemm.py) keeps the operands in the Infinity Cache and ranked a kernel with a shorter DMA lead 6-14 % AHEAD that
+is 20-25 % BEHIND here and in the step (round 3, the wave-specialised kernel of commit 10e1a6e)."""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -31,7 +33,7 @@ def run(kind, n=12):
 for kind, fl in (("qkv", 2 * M * 2304 * 768), ("out", 2 * M * 768 * 768)):
     res = {}
     for rnd in range(4):
-        for vn, cfg in (("base-nt", 257 + 1024), ("ws-nt", 129 + 1024), ("base", 257 + 2048)):
+        for vn, cfg in (("nt", 1 + 1024), ("plain", 1 + 2048), ("per-tile nt", 17 + 1024)):
             L.check(lib.czc_gemm_set_tile(cfg))
             t = run(kind)
             if rnd: res.setdefault(vn, []).append(t)
