@@ -402,16 +402,27 @@ def main():
 
     # per-operation table: a few more steps, OUTSIDE the timed region, with a hipEvent pair around every operation
     kernels = None
+    # (the per-operation event pairs mean something only while operations run one after another: the key encoder's
+    #  second stream is switched off for these extra steps)
+    overlap_was = getattr(model.module, "key_overlap", None)
+    if overlap_was is not None and args.kernel_table > 0:
+        model.module.key_overlap = False
     if rank == 0 and args.kernel_table > 0:
         L.check(lib.czc_prof_enable(1))
         for i in range(args.kernel_table):
             step(args.warmup + args.steps + i)
         torch.cuda.synchronize()
         kernels = kernel_table(L.prof_report(), args.kernel_table)
+        if os.environ.get("CZC_BENCH_ALLOPS"):       # dev: every operation of a step, largest first
+            for k in kernels:
+                log(f"op {k['name']:44s} x{k['calls_per_step']:6.1f} {k['us_per_call']:9.2f} us  {k['ms_per_step']:8.3f} ms/step  "
+                    + (f"{k['tflops']:7.1f} TF/s" if k['bound'] == 'mfma' else f"{k['gbps']:7.1f} GB/s"))
         L.check(lib.czc_prof_enable(0))
     elif args.kernel_table > 0:
         for i in range(args.kernel_table):     # the other ranks take the same collectives
             step(args.warmup + args.steps + i)
+    if overlap_was is not None:
+        model.module.key_overlap = overlap_was
 
     if rank == 0:
         log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
@@ -423,7 +434,9 @@ def main():
         # the commit of gemm_bf16.hip it was collected on, and a figure collected on another version of the kernel is
         # reported as null rather than passed off as current
         traffic, traffic_note = None, None
-        tpath = os.path.join(ROOT, "profiles", "r2_pmc_ffn_up.json")
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_ffn_up.json")))   # the newest round's collection
+        tpath = cands[-1] if cands else ""
         if os.path.exists(tpath):
             with open(tpath) as f:
                 pmc = json.load(f)
