@@ -138,7 +138,7 @@ static BwdLayout bwd_layout(const czc_bert_shape* s, int B, int S) {
   }
   int64_t sb = 0;
   auto need = [&](int Mo, int No) { int64_t v = (int64_t)dw_splits(Mo, No, M) * Mo * No * 4; if (v > sb) sb = v; };
-  need(3 * H, H); need(H, H); need(I, H); need(H, I);
+  need(3 * H, H); need(H, H); need(I, H); need(H, I); need(4 * H, H);
   b.slab_bytes = sb;
   b.slabs = take(sb);
   b.total = o;
@@ -370,6 +370,22 @@ extern "C" int czc_encoder_backward(const czc_bert_shape* s, const float* params
     RC(gemm(1, 1, EPI_F32, Mo, No, M, dY, ldy, X, ldx, slabs, No, nullptr, nullptr, nullptr, sp, st));
     return czc_reduce_slabs(slabs, sp, (int64_t)Mo * No, dst, accumulate, stream);
   };
+  // Two weight gradients that are neighbours in the flat array, one launch: dW[a | b] = [dYa | dYb]^T . [Xa | Xb] with
+  // rows [0, Ma) from (dYa, Xa) and rows [Ma, Ma + Mb) from (dYb, Xb) (GemmArgs::A2).  Used for [Wqkv | Wo]: the 768 x 768
+  // gradient alone has 9 output tiles -- 28-way split-K, 37 K-tiles per workgroup, 28 slabs: 745 TFLOP/s + 15 us of slab
+  // sums against 1 100-1 230 for its neighbours; as rows 2304 .. 3071 of one 3072 x 768 product it runs at their rate.
+  auto dweight2 = [&](int Ma, int Mb, int No, const uint16_t* dYa, int lda_, const uint16_t* Xa, int ldxa,
+                      const uint16_t* dYb, int ldb_, const uint16_t* Xb, int ldxb, float* dst) -> int {
+    const int Mo = Ma + Mb, sp = dw_splits(Mo, No, M);
+    GemmArgs g{};
+    g.A = (const bf16_t*)dYa; g.B = (const bf16_t*)Xa; g.lda = lda_; g.ldb = ldxa;
+    g.A2 = (const bf16_t*)dYb; g.B2 = (const bf16_t*)Xb; g.lda2 = ldb_; g.ldb2 = ldxb; g.g_rows = Ma;
+    g.C = slabs; g.M = Mo; g.N = No; g.K = M; g.ldc = No;
+    RC(gemm_dispatch(1, 1, EPI_F32, g, sp, st));
+    return czc_reduce_slabs(slabs, sp, (int64_t)Mo * No, dst, accumulate, stream);
+  };
+  // (the row tile is 256: the first product's rows must fill whole tiles; GF(WO) must follow GF(WQKV) -- it does, param_off)
+  const bool qkvo_together = (3 * H) % 256 == 0 && H % 8 == 0;
 
   // the gradient w.r.t. the input of layer `layer_hi` stays in scratch (g0) between ranged calls
   if (first) RC(czc_pool_backward(d_emb, FBUF(e.raw), mask, batch, seq, H, pooling, normalize, g0, stream));
@@ -387,7 +403,7 @@ extern "C" int czc_encoder_backward(const czc_bert_shape* s, const float* params
       // x1 = LN(drop(y1) + x[l])
       RC(czc_residual_ln_backward(X1, nullptr, BUF(w.y1), BUF(e.x[l]), FBUF(w.st1), M, H, PF(CZC_P_LN1W, l), ph, seed,
                                   SITE_H1(l), Z, Y, GF(CZC_P_LN1W, l), GF(CZC_P_LN1B, l), GF(CZC_P_BO, l), part_ln1, stream));
-      RC(dweight(H, H, Y, H, BUF(w.ctx), H, GF(CZC_P_WO, l)));
+      if (!qkvo_together) RC(dweight(H, H, Y, H, BUF(w.ctx), H, GF(CZC_P_WO, l)));
       RC(dinput(EPI_STORE, M, H, H, Y, H, CZC_P_WO, l, C, H, nullptr, nullptr));
       RC(czc_attention_backward_keep(BUF(w.qkv), mask, BUF(w.ctx), C, FBUF(w.lse), batch, seq, nh, pa, seed, SITE_ATTN(l),
                                      (w.keep >= 0 && pa > 0.f) ? (const uint32_t*)(ws + w.keep) : nullptr, delta, Q3,
@@ -403,7 +419,10 @@ extern "C" int czc_encoder_backward(const czc_bert_shape* s, const float* params
           {part_attn, ar, 3 * H, 3 * H, 3 * H, {GF(CZC_P_BQKV, l), nullptr, nullptr}}};
       RC(multi_reduce(jobs, 4, st));
     }
-    RC(dweight(3 * H, H, Q3, 3 * H, BUF(e.x[l]), H, GF(CZC_P_WQKV, l)));
+    if (qkvo_together)   // Y (the gradient at the attention output projection's output) is untouched since the LayerNorm backward
+      RC(dweight2(3 * H, H, H, Q3, 3 * H, BUF(e.x[l]), H, Y, H, BUF(w.ctx), H, GF(CZC_P_WQKV, l)));
+    else
+      RC(dweight(3 * H, H, Q3, 3 * H, BUF(e.x[l]), H, GF(CZC_P_WQKV, l)));
     RC(dinput(EPI_ADD, M, H, 3 * H, Q3, 3 * H, CZC_P_WQKV, l, g0, H, Z, nullptr));
   }
   if (last)

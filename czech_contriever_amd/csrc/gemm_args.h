@@ -6,6 +6,11 @@ namespace czc {
 
 struct GemmArgs {
   const bf16_t* A; const bf16_t* B;
+  // optional SECOND product in the same launch (EPI_F32 only): output rows [g_rows, M) are A2^T-side x B2 with leading
+  // dimensions of their own and the same N, K; g_rows is a multiple of the row tile.  The encoder's backward uses it for
+  // dW[qkv | o] = [dQKV | dY]^T . [x | ctx]: the two weight gradients are neighbours in the flat gradient array, and the
+  // 768 x 768 one alone has 9 output tiles (28-way split-K, 37 K-tiles per workgroup: 745 TFLOP/s against 1 100-1 230)
+  const bf16_t* A2; const bf16_t* B2; int lda2, ldb2, g_rows;
   void* C; void* C2;
   const float* bias; const bf16_t* aux;
   const float* rowv;     // per-row vector (head: lse)

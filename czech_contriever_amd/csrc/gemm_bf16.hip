@@ -251,18 +251,27 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  auto stage_at = [&](int r0, int c0, int t, int buf) {
-    unsigned char* ta = smem + buf * BUF_BYTES;
-    unsigned char* tb = ta + TILE_BYTES_A;
-    const int k0 = (kt_begin + t) * BK;
-    if (AL == 0) stage_kmajor<BM, CF::NW>(a.A, a.lda, r0, a.M, k0, a.K, ta, wave, lane);
-    else         stage_mnmajor<BM, CF::NW>(a.A, a.lda, r0, a.M, k0, a.K, ta, wave, lane);
-    if (BL == 0) stage_kmajor<BN, CF::NW>(a.B, a.ldb, c0, a.N, k0, a.K, tb, wave, lane);
-    else         stage_mnmajor<BN, CF::NW>(a.B, a.ldb, c0, a.N, k0, a.K, tb, wave, lane);
-  };
   int tm, tn;
   swizzle_tile(tile, ntiles, a.tiles_m, a.tiles_n, a.group_n, tm, tn);
   const int row0 = tm * BM, col0 = tn * BN;
+  // Two products in one launch (the f32 slab epilogue only; gemm_args.h): output rows from g_rows on are the SECOND
+  // product's, with operands, leading dimensions and row count of their own (same N and K).  gA .. aM are what the
+  // operand staging below uses; the output side keeps row0 and a.M.
+  const bool grp2 = EPI == EPI_F32 && a.A2 != nullptr && row0 >= a.g_rows;
+  const bf16_t* const gA = grp2 ? a.A2 : a.A;
+  const bf16_t* const gB = grp2 ? a.B2 : a.B;
+  const int glda = grp2 ? a.lda2 : a.lda, gldb = grp2 ? a.ldb2 : a.ldb;
+  const int arow0 = grp2 ? row0 - a.g_rows : row0;
+  const int aM = (EPI == EPI_F32 && a.A2 != nullptr) ? (grp2 ? a.M - a.g_rows : a.g_rows) : a.M;
+  auto stage_at = [&](int r0, int c0, int t, int buf) {   // (r0: operand rows, i.e. arow0 for the current tile)
+    unsigned char* ta = smem + buf * BUF_BYTES;
+    unsigned char* tb = ta + TILE_BYTES_A;
+    const int k0 = (kt_begin + t) * BK;
+    if (AL == 0) stage_kmajor<BM, CF::NW>(gA, glda, r0, aM, k0, a.K, ta, wave, lane);
+    else         stage_mnmajor<BM, CF::NW>(gA, glda, r0, aM, k0, a.K, ta, wave, lane);
+    if (BL == 0) stage_kmajor<BN, CF::NW>(gB, gldb, c0, a.N, k0, a.K, tb, wave, lane);
+    else         stage_mnmajor<BN, CF::NW>(gB, gldb, c0, a.N, k0, a.K, tb, wave, lane);
+  };
   if (!PREFETCH && tile != (int)blockIdx.x) __syncthreads();   // nobody still reads what the first DMA overwrites
 
   f32x4 acc[TM][TN];
@@ -281,22 +290,22 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   //  itself, is a plain multiply now)
   constexpr bool USE_FAST = true;
   constexpr bool SADDR = (AL == 1 && BL == 1);   // else: the same offsets added to the base on the VALU (2 instructions per piece)
-  const bool fast = USE_FAST && a.fast_addr && row0 + BM <= a.M && col0 + BN <= a.N;
+  const bool fast = USE_FAST && a.fast_addr && arow0 + BM <= aM && col0 + BN <= a.N;
   unsigned off_a[PER_A], off_b[PER_B];
 #pragma unroll
   for (int i = 0; i < PER_A; ++i)
-    off_a[i] = (AL == 0) ? piece_off_kmajor<BM, CF::NW>(a.lda, row0, wave, lane, i) : piece_off_mnmajor<BM, CF::NW>(a.lda, row0, wave, lane, i);
+    off_a[i] = (AL == 0) ? piece_off_kmajor<BM, CF::NW>(glda, arow0, wave, lane, i) : piece_off_mnmajor<BM, CF::NW>(glda, arow0, wave, lane, i);
 #pragma unroll
   for (int i = 0; i < PER_B; ++i)
-    off_b[i] = (BL == 0) ? piece_off_kmajor<BN, CF::NW>(a.ldb, col0, wave, lane, i) : piece_off_mnmajor<BN, CF::NW>(a.ldb, col0, wave, lane, i);
+    off_b[i] = (BL == 0) ? piece_off_kmajor<BN, CF::NW>(gldb, col0, wave, lane, i) : piece_off_mnmajor<BN, CF::NW>(gldb, col0, wave, lane, i);
   auto fast_piece = [&](int t, int buf, int p, auto& pin, auto& after) {
     const int k0 = (kt_begin + t) * BK;
     if (p < PER_A) {
-      const char* base = (const char*)a.A + ((AL == 0) ? (size_t)k0 * 2 : (size_t)k0 * a.lda * 2);
+      const char* base = (const char*)gA + ((AL == 0) ? (size_t)k0 * 2 : (size_t)k0 * glda * 2);
       if (SADDR) glds16_sbase(off_a[p], base, (lptr_t)(smem + buf * BUF_BYTES + (wave * PER_A + p) * 1024), pin, after);
       else glds16_pin(base + off_a[p], (lptr_t)(smem + buf * BUF_BYTES + (wave * PER_A + p) * 1024), pin, after);
     } else {
-      const char* base = (const char*)a.B + ((BL == 0) ? (size_t)k0 * 2 : (size_t)k0 * a.ldb * 2);
+      const char* base = (const char*)gB + ((BL == 0) ? (size_t)k0 * 2 : (size_t)k0 * gldb * 2);
       if (SADDR) glds16_sbase(off_b[p - PER_A], base, (lptr_t)(smem + buf * BUF_BYTES + TILE_BYTES_A + (wave * PER_B + p - PER_A) * 1024), pin, after);
       else glds16_pin(base + off_b[p - PER_A], (lptr_t)(smem + buf * BUF_BYTES + TILE_BYTES_A + (wave * PER_B + p - PER_A) * 1024), pin, after);
     }
@@ -310,18 +319,18 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   };
   auto stage = [&](int t, int buf) {
     if (USE_FAST && t < ntf) stage_fast(t, buf);
-    else stage_at(row0, col0, t, buf);
+    else stage_at(arow0, col0, t, buf);
   };
   auto stage_piece = [&](int t, int buf, int p, bf16x8& pin, bf16x8& after) {
     unsigned char* ta = smem + buf * BUF_BYTES;
     unsigned char* tb = ta + TILE_BYTES_A;
     const int k0 = (kt_begin + t) * BK;
     if (p < PER_A) {
-      if (AL == 0) stage_kmajor_piece<BM, CF::NW>(a.A, a.lda, row0, a.M, k0, a.K, ta, wave, lane, p, pin, after);
-      else         stage_mnmajor_piece<BM, CF::NW>(a.A, a.lda, row0, a.M, k0, a.K, ta, wave, lane, p, pin, after);
+      if (AL == 0) stage_kmajor_piece<BM, CF::NW>(gA, glda, arow0, aM, k0, a.K, ta, wave, lane, p, pin, after);
+      else         stage_mnmajor_piece<BM, CF::NW>(gA, glda, arow0, aM, k0, a.K, ta, wave, lane, p, pin, after);
     } else {
-      if (BL == 0) stage_kmajor_piece<BN, CF::NW>(a.B, a.ldb, col0, a.N, k0, a.K, tb, wave, lane, p - PER_A, pin, after);
-      else         stage_mnmajor_piece<BN, CF::NW>(a.B, a.ldb, col0, a.N, k0, a.K, tb, wave, lane, p - PER_A, pin, after);
+      if (BL == 0) stage_kmajor_piece<BN, CF::NW>(gB, gldb, col0, a.N, k0, a.K, tb, wave, lane, p - PER_A, pin, after);
+      else         stage_mnmajor_piece<BN, CF::NW>(gB, gldb, col0, a.N, k0, a.K, tb, wave, lane, p - PER_A, pin, after);
     }
   };
 
@@ -387,11 +396,11 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
     for (int i = 0; i < 2; ++i) {
       const int q = 16 * h + 2 * wave + i;
       if (opnd == 0) {
-        if (AL == 0) stage_kmajor_q(a.A, a.lda, r0, a.M, k0, a.K, ta, q, lane, np, np2);
-        else         stage_mnmajor_q(a.A, a.lda, r0, a.M, k0, a.K, ta, q, lane, np, np2);
+        if (AL == 0) stage_kmajor_q(gA, glda, r0, aM, k0, a.K, ta, q, lane, np, np2);
+        else         stage_mnmajor_q(gA, glda, r0, aM, k0, a.K, ta, q, lane, np, np2);
       } else {
-        if (BL == 0) stage_kmajor_q(a.B, a.ldb, c0, a.N, k0, a.K, tb, q, lane, np, np2);
-        else         stage_mnmajor_q(a.B, a.ldb, c0, a.N, k0, a.K, tb, q, lane, np, np2);
+        if (BL == 0) stage_kmajor_q(gB, gldb, c0, a.N, k0, a.K, tb, q, lane, np, np2);
+        else         stage_mnmajor_q(gB, gldb, c0, a.N, k0, a.K, tb, q, lane, np, np2);
       }
     }
   };
@@ -400,10 +409,10 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
   for (int hi = 0; hi < 4; ++hi) {
     const int q = 16 * (hi >> 1) + 2 * wave + (hi & 1);
-    poff_a[hi] = (AL == 0) ? piece_off_kmajor_q(a.lda, row0, q, lane) : piece_off_mnmajor_q(a.lda, row0, q, lane);
-    poff_b[hi] = (BL == 0) ? piece_off_kmajor_q(a.ldb, col0, q, lane) : piece_off_mnmajor_q(a.ldb, col0, q, lane);
+    poff_a[hi] = (AL == 0) ? piece_off_kmajor_q(glda, arow0, q, lane) : piece_off_mnmajor_q(glda, arow0, q, lane);
+    poff_b[hi] = (BL == 0) ? piece_off_kmajor_q(gldb, col0, q, lane) : piece_off_mnmajor_q(gldb, col0, q, lane);
   }
-  const bool pfast = a.fast_addr && row0 + BM <= a.M && col0 + BN <= a.N;
+  const bool pfast = a.fast_addr && arow0 + BM <= aM && col0 + BN <= a.N;
   const int pntf = pfast ? max(0, min(nt, a.K / BK - kt_begin)) : 0;   // K-tiles [0, pntf) are full
   auto stage_half_fast = [&](int opnd, int t, int h) {
     const int k0 = (kt_begin + t) * BK;
@@ -412,12 +421,12 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
     for (int i = 0; i < 2; ++i) {
       const int q = 16 * h + 2 * wave + i;
       if (opnd == 0) {
-        const char* base = (const char*)a.A + ((AL == 0) ? (size_t)k0 * 2 : (size_t)k0 * a.lda * 2);
+        const char* base = (const char*)gA + ((AL == 0) ? (size_t)k0 * 2 : (size_t)k0 * glda * 2);
         lptr_t dst = (lptr_t)(smem + (t & 1) * BUF_BYTES + q * 1024);
         if (AL == 1 && BL == 1) glds16_sbase(poff_a[2 * h + i], base, dst, np, np2);
         else glds16_pin(base + poff_a[2 * h + i], dst, np, np2);
       } else {
-        const char* base = (const char*)a.B + ((BL == 0) ? (size_t)k0 * 2 : (size_t)k0 * a.ldb * 2);
+        const char* base = (const char*)gB + ((BL == 0) ? (size_t)k0 * 2 : (size_t)k0 * gldb * 2);
         lptr_t dst = (lptr_t)(smem + (t & 1) * BUF_BYTES + TILE_BYTES_A + q * 1024);
         if (AL == 1 && BL == 1) glds16_sbase(poff_b[2 * h + i], base, dst, np, np2);
         else glds16_pin(base + poff_b[2 * h + i], dst, np, np2);
@@ -426,7 +435,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   };
   auto sh = [&](int opnd, int t, int h) {
     if (t < pntf) stage_half_fast(opnd, t, h);
-    else if (t < nt) stage_half(row0, col0, opnd, t, h);
+    else if (t < nt) stage_half(arow0, col0, opnd, t, h);
   };
   bf16x8 fa[8], fbl[4], fbh[4];   // A: [ks*4 + i] of the current row half; B lo / hi column pairs: [ks*2 + j]
   auto load_a = [&](int t, int qi) {
@@ -565,7 +574,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                      \
     __syncthreads();                                                                                 \
     __builtin_amdgcn_sched_barrier(0);   /* phases 0-2 and phase 3 are scheduled as separate regions */ \
-    if ((STAGE) && !SPREAD) { if (FAST) stage_fast(t + 2, buf); else stage_at(row0, col0, t + 2, buf); } \
+    if ((STAGE) && !SPREAD) { if (FAST) stage_fast(t + 2, buf); else stage_at(arow0, col0, t + 2, buf); } \
     __builtin_amdgcn_sched_barrier(0);                                                               \
     /* (after the last tile these read the other buffer's stale bytes: never used) */               \
     read_a(fa0, buf ^ 1, 0, 0);                                                                      \
@@ -897,7 +906,9 @@ static int launch_cfg(GemmArgs a, int splits, hipStream_t st) {
   {
     const size_t ea = (AL == 0) ? (size_t)a.M * a.lda : (size_t)a.K * a.lda;   // elements spanned by A / B
     const size_t eb = (BL == 0) ? (size_t)a.N * a.ldb : (size_t)a.K * a.ldb;
-    a.fast_addr = (ea * 2 < (1ull << 31) && eb * 2 < (1ull << 31)) ? 1 : 0;
+    const size_t ea2 = a.A2 ? ((AL == 0) ? (size_t)a.M * a.lda2 : (size_t)a.K * a.lda2) : 0;
+    const size_t eb2 = a.A2 ? ((BL == 0) ? (size_t)a.N * a.ldb2 : (size_t)a.K * a.ldb2) : 0;
+    a.fast_addr = (ea * 2 < (1ull << 31) && eb * 2 < (1ull << 31) && ea2 * 2 < (1ull << 31) && eb2 * 2 < (1ull << 31)) ? 1 : 0;
   }
   // wide outputs (FFN-up, its backward): six column tiles per sweep keep that group's B panels (6 x 256 x K) in L2 for
   // all the row tiles under them (PMC: FETCH 558 -> 433 MB per FFN-up launch, -2 % time); split-K products and
@@ -953,7 +964,7 @@ int gemm_dispatch(int al, int bl, int epi, GemmArgs a, int splitk, hipStream_t s
                    a.N == p.N && a.K == p.K;
   if (hit) CZC_HIP(hipEventRecord(p.ev[2 * p.count], st));
   char pname[96];
-  if (g_prof_on) snprintf(pname, sizeof(pname), "gemm a%d b%d epi%d %dx%dx%d%s", al, bl, epi, a.M, a.N, a.K, splitk > 1 ? " splitk" : "");
+  if (g_prof_on) snprintf(pname, sizeof(pname), "gemm a%d b%d epi%d %dx%dx%d%s%s", al, bl, epi, a.M, a.N, a.K, splitk > 1 ? " splitk" : "", a.A2 ? " (two products)" : "");
   const double outb = (epi == EPI_F32 ? 4.0 * splitk : (epi == EPI_LSE || epi == EPI_FILTER) ? 0.0 : 2.0) *
                       (epi == EPI_BIAS_GELU ? 2.0 : 1.0);
   ProfScope prof(st, g_prof_on ? pname : "", 2.0 * a.M * (double)a.N * a.K,
@@ -982,6 +993,12 @@ static int gemm_dispatch_inner(int al, int bl, int epi, GemmArgs a, int splitk, 
     CZC_REQUIRE((size_t)a.M * (size_t)a.ldc * 2u < 0xfffffff0ull,
                 "czc_gemm: a bf16 output of %d x %d exceeds the 4 GiB a buffer descriptor addresses", a.M, a.ldc);
   CZC_REQUIRE(splitk == 1 || epi == EPI_F32, "czc_gemm: split-K needs the f32 slab epilogue");
+  if (a.A2) {
+    CZC_REQUIRE(epi == EPI_F32 && a.B2 && a.g_rows > 0 && a.g_rows < a.M && a.g_rows % 256 == 0 && (a.lda2 % 8) == 0 && (a.ldb2 % 8) == 0 &&
+                ((uintptr_t)a.A2 % 16) == 0 && ((uintptr_t)a.B2 % 16) == 0,
+                "czc_gemm: the second product needs the f32 slab epilogue, both operands, g_rows = %d a multiple of 256 inside (0, M)", a.g_rows);
+    a.cfg = 1;   // (the row split is laid out for the 256-row tile)
+  }
   const int kt = ceil_div(a.K, BK);
   a.ktiles_per_split = ceil_div(kt, splitk);
   switch (epi) {
@@ -1034,6 +1051,16 @@ extern "C" int czc_gemm_bf16(int a_layout, int b_layout, int epilogue, int M, in
   a.A = A; a.B = B; a.C = C; a.C2 = C2; a.bias = bias; a.aux = aux;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   return gemm_dispatch(a_layout, b_layout, epilogue, a, splitk, (hipStream_t)stream);
+}
+
+extern "C" int czc_gemm_wgrad_pair(int M1, int M2, int N, int K, const uint16_t* A1, int lda1, const uint16_t* B1, int ldb1,
+                                   const uint16_t* A2, int lda2, const uint16_t* B2, int ldb2, float* C, int splitk,
+                                   czc_stream_t stream) {
+  GemmArgs a{};
+  a.A = A1; a.B = B1; a.lda = lda1; a.ldb = ldb1;
+  a.A2 = A2; a.B2 = B2; a.lda2 = lda2; a.ldb2 = ldb2; a.g_rows = M1;
+  a.C = C; a.M = M1 + M2; a.N = N; a.K = K; a.ldc = N;
+  return gemm_dispatch(CZC_LAYOUT_MNMAJOR, CZC_LAYOUT_MNMAJOR, EPI_F32, a, splitk, (hipStream_t)stream);
 }
 
 extern "C" int czc_gemm_set_tile(int cfg) {

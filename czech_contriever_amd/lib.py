@@ -55,6 +55,7 @@ SIGNATURES = {
     "czc_cast_bf16": (i32, [vp, vp, i64, vp]),
     "czc_gemm_bf16": (i32, [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, vp]),
     "czc_gemm_set_tile": (i32, [i32]),
+    "czc_gemm_wgrad_pair": (i32, [i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp]),
     "czc_probe_arm": (i32, [i32, i32, i32, i32, i32, i32, i32]),
     "czc_probe_read": (i32, [C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "czc_prof_enable": (i32, [i32]),

@@ -217,6 +217,13 @@ int czc_gemm_bf16(int a_layout, int b_layout, int epilogue, int M, int N, int K,
                   void* C, int ldc, const float* bias, const uint16_t* aux, void* C2,
                   int splitk, czc_stream_t stream);
 
+/* Two weight-gradient products in ONE launch: C f32 [splitk][M1 + M2][N], rows [0, M1) = A1^T . B1, rows [M1, M1 + M2) =
+ * A2^T . B2, all operands MN-major ([K][M] / [K][N]: the reduction runs over tokens), M1 % 256 == 0.  The encoder's
+ * backward computes dW[qkv | o] this way (they are neighbours in the flat gradient array). */
+int czc_gemm_wgrad_pair(int M1, int M2, int N, int K, const uint16_t* A1, int lda1, const uint16_t* B1, int ldb1,
+                        const uint16_t* A2, int lda2, const uint16_t* B2, int ldb2, float* C, int splitk,
+                        czc_stream_t stream);
+
 /* Tile configuration used by every later GEMM launch that does not choose one itself:
  * 0 = built-in choice, 1 = 256x256 tile (8 waves, 1 workgroup/CU), 2 = 128x128 (4 waves, 2 workgroups/CU);
  * + 16 = one workgroup per output tile instead of workgroups that walk over several tiles (tuning A/B; launches beside

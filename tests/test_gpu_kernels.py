@@ -591,3 +591,23 @@ def test_infonce_saturated_positive_is_exactly_zero(ops):
         assert float(stats[0]) == 0.0, float(stats[0])
         assert float(dq.abs().max()) == 0.0, float(dq.abs().max())
         assert float(stats[1]) == 100.0
+
+
+@pytest.mark.parametrize("M1,M2,N,K,sp", [(2304, 768, 768, 3000, 7), (3072, 1024, 1024, 81, 2), (256, 40, 320, 700, 3)])
+def test_gemm_two_weight_gradients_in_one_launch(ops, M1, M2, N, K, sp):
+    """czc_gemm_wgrad_pair: rows [0, M1) = A1^T . B1, rows [M1, M1 + M2) = A2^T . B2 in one split-K launch (the encoder's
+    dW[qkv | o]) must equal the two products launched on their own, slab for slab and bit for bit."""
+    from czech_contriever_amd import lib as L
+    lib = L.load()
+    a1, b1 = rnd(K, M1, seed=61, scale=0.5, dtype=BF16), rnd(K, N, seed=62, scale=0.5, dtype=BF16)
+    a2, b2 = rnd(K, M2, seed=63, scale=0.5, dtype=BF16), rnd(K, N, seed=64, scale=0.5, dtype=BF16)
+    out = torch.full((sp, M1 + M2, N), float("nan"), device=dev())
+    L.check(lib.czc_gemm_wgrad_pair(M1, M2, N, K, a1.data_ptr(), M1, b1.data_ptr(), N, a2.data_ptr(), M2, b2.data_ptr(), N,
+                                    out.data_ptr(), sp, L.stream_ptr()))
+    r1 = ops.gemm(a1, b1, a_layout=1, b_layout=1, epilogue="f32", M=M1, N=N, K=K, splitk=sp)
+    r2 = ops.gemm(a2, b2, a_layout=1, b_layout=1, epilogue="f32", M=M2, N=N, K=K, splitk=sp)
+    assert torch.isfinite(out).all()
+    # the split-K ranges are those of the joint launch (same K, same split count): slab for slab the same MFMA chains
+    assert torch.equal(out[:, :M1], r1) and torch.equal(out[:, M1:], r2)
+    ref = torch.cat([a1.float().t() @ b1.float(), a2.float().t() @ b2.float()])
+    report("pair", out.sum(0), ref, 2e-3 * math.sqrt(K), 1e-4)

@@ -5,10 +5,10 @@ set -o pipefail
 R=$PWD
 O=$R/gpurun_out/${TAG:-r3}_final
 mkdir -p $O
+# (below the first line per-kernel durations and counters are collected with the key encoder's second stream off:
+#  kernels of two streams that share the CUs would each be charged the other's time)
 python bench.py > $O/bench_default.json 2> $O/bench_default.err && tail -2 $O/bench_default.err && \
 cd /tmp && export TMPDIR=/tmp && export CZC_KEY_OVERLAP=0 && \
-# (per-kernel durations and counters are collected with the key encoder's second stream off: kernels of two streams that
-#  share the CUs would each be charged the other's time)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --kernel-table 0 > $O/stats.log 2>&1 && echo stats ok && \
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --kernel-table 0 > $O/pmc_fetch.log 2>&1 && echo fetch ok && \
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --kernel-table 0 > $O/pmc_write.log 2>&1 && echo write ok && \
