@@ -112,8 +112,10 @@ class MoCo(nn.Module):
         self.key_gather_split = True   # data parallel: last key-encoder layer in two halves, first half's all-gather under it
         # one GPU: the key encoder's pass (EMA + forward, nothing differentiates through it) is independent of the query
         # encoder's forward; on a second HIP stream the two passes' kernels fill each other's launch gaps and tails
-        # (interleaved A/B at the headline shapes: 55.79 -> 55.63 ms per step; CZC_KEY_OVERLAP=0 switches it off)
-        self.key_overlap = os.environ.get("CZC_KEY_OVERLAP", "1") == "1"
+        # (interleaved A/B at the headline shapes: 55.79 -> 55.63 ms per step.  Off unless CZC_KEY_OVERLAP=1: 0.3 % is inside
+        #  the spread between devices, and kernels of two streams that share the CUs stretch each other's durations, which
+        #  makes every per-kernel figure -- hipEvent probes, rocprofv3 -- read high)
+        self.key_overlap = os.environ.get("CZC_KEY_OVERLAP", "0") == "1"
         self._key_stream = None
 
         retriever, tokenizer = self._load_retriever(opt.retriever_model_id, pooling=opt.pooling,
