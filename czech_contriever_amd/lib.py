@@ -108,7 +108,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError = a symbol czc.h declares is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.czc_abi_version() != 4:
+    if lib.czc_abi_version() != 5:
         raise RuntimeError("libczc.so ABI version mismatch")
     _lib = lib
     return lib

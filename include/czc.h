@@ -30,7 +30,7 @@ extern "C" {
 #define CZC_ERR_INVALID 1
 #define CZC_ERR_HIP 2
 
-#define CZC_ABI_VERSION 4
+#define CZC_ABI_VERSION 5
 
 typedef void* czc_stream_t; /* hipStream_t */
 typedef void* czc_event_t;  /* hipEvent_t (timing disabled) */

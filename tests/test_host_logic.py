@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(lib.LIB_PATH)
     for name in declared:
         getattr(raw, name)
-    assert L.czc_abi_version() == 4
+    assert L.czc_abi_version() == 5
 
 
 def test_argument_checks_fail_without_launching():
