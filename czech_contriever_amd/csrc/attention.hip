@@ -294,8 +294,14 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_res_kernel(const AttnArgs a) 
     const int id = tid + 512 * i, row = id >> 3, c = id & 7;
     kv[i] = vv[i] = (uint4){0u, 0u, 0u, 0u};
     if (row < S) {
-      kv[i] = *(const uint4*)(base + a.H + (size_t)row * H3 + c * 8);
-      vv[i] = *(const uint4*)(base + 2 * a.H + (size_t)row * H3 + c * 8);
+      // streaming (nt) reads: K and V are read once per kernel, and without them in its way the context rows this kernel
+      // writes stay in the Infinity Cache for the output projection that follows (forward 112.9 -> 110.2 us, the
+      // projection 88.1 -> 86.8, interleaved in the step)
+      typedef __attribute__((ext_vector_type(4))) unsigned u4v;
+      const u4v k_ = __builtin_nontemporal_load((const u4v*)(base + a.H + (size_t)row * H3 + c * 8));
+      const u4v v_ = __builtin_nontemporal_load((const u4v*)(base + 2 * a.H + (size_t)row * H3 + c * 8));
+      kv[i] = make_uint4(k_[0], k_[1], k_[2], k_[3]);
+      vv[i] = make_uint4(v_[0], v_[1], v_[2], v_[3]);
     }
   }
   bf16x8 bq[4];
