@@ -36,6 +36,31 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(suffix: str, defines, verbose: bool = True) -> str:
+    """A second library libczc_<suffix>.so from the same sources with extra -D switches (kernel A/B on one device:
+    CZC_LIB_VARIANT=<suffix> makes lib.load() take it).  Objects go to build_<suffix>/; nothing of the product build is touched."""
+    obj = OBJ + "_" + suffix
+    os.makedirs(obj, exist_ok=True)
+    out = os.path.join(HERE, f"libczc_{suffix}.so")
+
+    def one(src):
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(obj, os.path.splitext(src)[0] + ".o")
+        cmd = [_hipcc()] + FLAGS + list(defines) + EXTRA_FLAGS.get(src, []) + (["-x", "hip"] if sp.endswith(".cpp") else []) + ["-c", sp, "-o", op]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {sp}:\n{r.stdout}\n{r.stderr}")
+        return op
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(one, SOURCES))
+    r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"[czc build] linked {out}", file=sys.stderr)
+    return out
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
@@ -71,4 +96,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--variant" in sys.argv:       # python -m czech_contriever_amd.build --variant nt -DATT_BWD_NT=1
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith("-D")]))
+    else:
+        print(build(force="--force" in sys.argv))

@@ -1040,32 +1040,37 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const AttnArgs a
 //      dQ tiles 2 x 4 KB (the seam's column-sum partials reuse them) | K staging 32 KB | V staging 32 KB | sums 2 KB.
 // ---------------------------------------------------------------------------------------------
 typedef void __attribute__((address_space(3)))* att_lptr_t;
+#ifdef ATT_BWD_NT   // A/B build: streaming policy for the backward's LDS-DMA operands
+#define ATT_POL " nt"
+#else
+#define ATT_POL ""
+#endif
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"   // m0 is ours to set here
 __device__ __forceinline__ void att_dma16(const void* src, unsigned dst) {   // 16 B per lane -> dst + 16 * lane
   const unsigned l = __builtin_amdgcn_readfirstlane(dst);   // LDS byte address (wave-uniform)
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(l) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ATT_POL ::"v"(src), "s"(l) : "memory", "m0");
 }
 __device__ __forceinline__ void att_dma4(const void* src, unsigned dst) {    // 4 B per lane -> dst + 4 * lane
   const unsigned l = __builtin_amdgcn_readfirstlane(dst);   // LDS byte address (wave-uniform)
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(l) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ATT_POL ::"v"(src), "s"(l) : "memory", "m0");
 }
 // the same from a wave-uniform 64-bit base (scalar registers) plus a 32-bit per-lane byte offset: the lane part of a piece's
 // address never changes, so the step loop spends scalar adds on addresses instead of 64-bit vector arithmetic
 __device__ __forceinline__ void att_dma16_s(unsigned off, const void* base, unsigned dst) {
   const unsigned l = __builtin_amdgcn_readfirstlane(dst);   // LDS byte address (wave-uniform)
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(l) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ATT_POL ::"v"(off), "s"(base), "s"(l) : "memory", "m0");
 }
 // Two pieces to dst and dst + 1024 behind ONE write of M0: the instruction's immediate offset moves both the source and the
 // LDS address, so the second lane offset comes in 1024 bytes short (off1m = off1 - 1024).
 __device__ __forceinline__ void att_dma16_s2(unsigned off0, unsigned off1m, const void* base, unsigned dst) {
   const unsigned l = __builtin_amdgcn_readfirstlane(dst);
-  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024"
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ATT_POL "\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024" ATT_POL
                ::"v"(off0), "v"(off1m), "s"(base), "s"(l) : "memory", "m0");
 }
 __device__ __forceinline__ void att_dma4_s(unsigned off, const void* base, unsigned dst) {
   const unsigned l = __builtin_amdgcn_readfirstlane(dst);   // LDS byte address (wave-uniform)
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(off), "s"(base), "s"(l) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ATT_POL ::"v"(off), "s"(base), "s"(l) : "memory", "m0");
 }
 #pragma clang diagnostic pop
 // The mask-byte load of the streaming kernel is inline asm as well: the compiler's wait-count pass knows nothing of the DMA

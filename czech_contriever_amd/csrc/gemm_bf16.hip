@@ -25,6 +25,8 @@
 // The MFMA is issued as D = B_frag x A_frag, i.e. the accumulator tile is C^T: a lane owns one
 // output row m and four consecutive columns n, so bias loads are float4 and the bf16 tile is put
 // into LDS with 8-byte writes, then streamed out as whole 128-B row segments.
+#include <stdlib.h>
+
 #include "czc_common.h"
 #include "gemm_args.h"
 
@@ -1028,12 +1030,22 @@ static int gemm_dispatch_inner(int al, int bl, int epi, GemmArgs a, int splitk, 
 }
 
 // slabs reduce:  dst (+)= sum_z slabs[z]
+// V = 1: four slabs' loads in flight per thread (the plain loop waits for each slab's load before the next: 15.0 -> 14.3 us)
+template <int V>
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslabs, int64_t n4, float* __restrict__ dst,
                                     int accumulate) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     f32x4 s = accumulate ? ((const f32x4*)dst)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < nslabs; ++z) s += ((const f32x4*)slabs)[(int64_t)z * n4 + i];
+    int z = 0;
+    if (V == 1) {
+      for (; z + 4 <= nslabs; z += 4) {   // same order of additions as the plain loop: results stay bit-identical
+        const f32x4 a = ((const f32x4*)slabs)[(int64_t)z * n4 + i], b = ((const f32x4*)slabs)[(int64_t)(z + 1) * n4 + i];
+        const f32x4 c = ((const f32x4*)slabs)[(int64_t)(z + 2) * n4 + i], d = ((const f32x4*)slabs)[(int64_t)(z + 3) * n4 + i];
+        s += a; s += b; s += c; s += d;
+      }
+    }
+    for (; z < nslabs; ++z) s += ((const f32x4*)slabs)[(int64_t)z * n4 + i];
     ((f32x4*)dst)[i] = s;
   }
 }
@@ -1115,8 +1127,7 @@ extern "C" int czc_reduce_slabs(const float* slabs, int nslabs, int64_t n, float
   const int64_t n4 = n / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slabs, nslabs, n4, dst,
-                     accumulate);
+  hipLaunchKernelGGL(reduce_slabs_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slabs, nslabs, n4, dst, accumulate);
   CZC_LAUNCH_CHECK();
   return CZC_OK;
 }

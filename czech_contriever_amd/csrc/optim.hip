@@ -3,6 +3,8 @@
 // Each runs as ONE launch over all 108.9 M elements (the reference issues ~600 tiny launches for
 // the EMA alone, src/moco.py:260-269), 16 B per lane per access, grid-stride, and refreshes the
 // bf16 mirror of the matrix region in the same pass so no separate cast pass is needed.
+#include <stdlib.h>
+
 #include "czc_common.h"
 
 namespace czc {
@@ -16,18 +18,35 @@ __device__ __forceinline__ void st_bf4g(bf16_t* p, f32x4 v) {
 
 // pk = pk*m + pq*(1-m): two rounded products and one rounded add, exactly like
 // `param_k.data * m + param_q.data * (1. - m)` in torch (no fused multiply-add).
+template <int V>   // V & 1: streaming (nt) loads and stores of the fp32 arrays; V & 2: two vectors per thread and iteration
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ pk, const float* __restrict__ pq, int64_t n4,
                                                   int64_t n, float m, float om, bf16_t* __restrict__ pk_bf,
                                                   int64_t n_bf) {
 #pragma clang fp contract(off)  // the two products must round separately (no FMA), as torch computes them
+  constexpr bool NT = (V & 1) != 0;
+  constexpr int U = (V & 2) ? 2 : 1;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const f32x4 a = ((const f32x4*)pk)[i], b = ((const f32x4*)pq)[i];
-    f32x4 r;
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += stride * U) {
+    f32x4 a[U], b[U];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const float p1 = a[j] * m, p2 = b[j] * om; r[j] = p1 + p2; }
-    ((f32x4*)pk)[i] = r;
-    if (i * 4 + 3 < n_bf) st_bf4g(pk_bf + i * 4, r);
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * stride;
+      if (i < n4) {
+        a[u] = NT ? __builtin_nontemporal_load((const f32x4*)pk + i) : ((const f32x4*)pk)[i];
+        b[u] = NT ? __builtin_nontemporal_load((const f32x4*)pq + i) : ((const f32x4*)pq)[i];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * stride;
+      if (i < n4) {
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float p1 = a[u][j] * m, p2 = b[u][j] * om; r[j] = p1 + p2; }
+        if (NT) __builtin_nontemporal_store(r, (f32x4*)pk + i); else ((f32x4*)pk)[i] = r;
+        if (i * 4 + 3 < n_bf) st_bf4g(pk_bf + i * 4, r);
+      }
+    }
   }
   // tail (n not a multiple of 4)
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
@@ -44,25 +63,49 @@ struct AdamArgs {
   float one_minus_b1, one_minus_b2, step_size, inv_bc2_sqrt, grad_scale;
 };
 
+template <int V>   // as ema_kernel
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, int64_t n4, int64_t n,
                                                     AdamArgs a, const float* __restrict__ clip_coef,
                                                     bf16_t* __restrict__ p_bf, int64_t n_bf) {
+  constexpr bool NT = (V & 1) != 0;
+  constexpr int U = (V & 2) ? 2 : 1;
   const float gs = a.grad_scale * (clip_coef ? clip_coef[0] : 1.0f);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    f32x4 pp = ((const f32x4*)p)[i], gg = ((const f32x4*)g)[i] * gs, mm = ((const f32x4*)m)[i], vv = ((const f32x4*)v)[i];
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += stride * U) {
+    f32x4 pp[U], gg[U], mm[U], vv[U];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float x = pp[j] * a.wd_factor;
-      const float m1 = mm[j] + (gg[j] - mm[j]) * a.one_minus_b1;  // lerp, as torch
-      const float v1 = vv[j] * a.beta2 + gg[j] * gg[j] * a.one_minus_b2;
-      const float denom = sqrtf(v1) * a.inv_bc2_sqrt + a.eps;
-      x -= a.step_size * (m1 / denom);
-      pp[j] = x; mm[j] = m1; vv[j] = v1;
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * stride;
+      if (i < n4) {
+        pp[u] = NT ? __builtin_nontemporal_load((const f32x4*)p + i) : ((const f32x4*)p)[i];
+        gg[u] = (NT ? __builtin_nontemporal_load((const f32x4*)g + i) : ((const f32x4*)g)[i]) * gs;
+        mm[u] = NT ? __builtin_nontemporal_load((const f32x4*)m + i) : ((const f32x4*)m)[i];
+        vv[u] = NT ? __builtin_nontemporal_load((const f32x4*)v + i) : ((const f32x4*)v)[i];
+      }
     }
-    ((f32x4*)p)[i] = pp; ((f32x4*)m)[i] = mm; ((f32x4*)v)[i] = vv;
-    if (i * 4 + 3 < n_bf) st_bf4g(p_bf + i * 4, pp);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * stride;
+      if (i < n4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float x = pp[u][j] * a.wd_factor;
+          const float m1 = mm[u][j] + (gg[u][j] - mm[u][j]) * a.one_minus_b1;  // lerp, as torch
+          const float v1 = vv[u][j] * a.beta2 + gg[u][j] * gg[u][j] * a.one_minus_b2;
+          const float denom = sqrtf(v1) * a.inv_bc2_sqrt + a.eps;
+          x -= a.step_size * (m1 / denom);
+          pp[u][j] = x; mm[u][j] = m1; vv[u][j] = v1;
+        }
+        if (NT) {
+          __builtin_nontemporal_store(pp[u], (f32x4*)p + i); __builtin_nontemporal_store(mm[u], (f32x4*)m + i);
+          __builtin_nontemporal_store(vv[u], (f32x4*)v + i);
+        } else {
+          ((f32x4*)p)[i] = pp[u]; ((f32x4*)m)[i] = mm[u]; ((f32x4*)v)[i] = vv[u];
+        }
+        if (i * 4 + 3 < n_bf) st_bf4g(p_bf + i * 4, pp[u]);
+      }
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const int64_t i = (n4 << 2) + threadIdx.x;
@@ -132,7 +175,9 @@ extern "C" int czc_ema_update(float* pk, const float* pq, int64_t n, float m, fl
               (long long)n, (long long)n_bf16);
   CZC_REQUIRE(((uintptr_t)pk % 16) == 0 && ((uintptr_t)pq % 16) == 0, "czc_ema_update: arrays must be 16-byte aligned");
   ProfScope prof((hipStream_t)stream, "ema", 0.0, 12.0 * n + 2.0 * (pk_bf16 ? n_bf16 : 0));
-  hipLaunchKernelGGL(ema_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, pk, pq, n / 4, n, m,
+// streaming loads / stores of the fp32 arrays (read and written once; 254-264 -> 251-256 us), one vector per thread and
+  // iteration (two: 300 us)
+  hipLaunchKernelGGL(ema_kernel<1>, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, pk, pq, n / 4, n, m,
                      one_minus_m, pk_bf16, pk_bf16 ? n_bf16 : 0);
   CZC_LAUNCH_CHECK();
   return CZC_OK;
@@ -156,7 +201,9 @@ extern "C" int czc_adamw_step(float* p, const float* g, float* m, float* v, int6
   a.step_size = (float)((double)lr / bc1);
   a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
   a.grad_scale = grad_scale;
-  hipLaunchKernelGGL(adamw_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, n, a,
+// streaming loads / stores and two vectors per thread and iteration (eight loads in flight): 590-628 -> 549-553 us
+  // in the step (either alone: 595)
+  hipLaunchKernelGGL(adamw_kernel<3>, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, n, a,
                      clip_coef_dev, p_bf16, p_bf16 ? n_bf16 : 0);
   CZC_LAUNCH_CHECK();
   return CZC_OK;

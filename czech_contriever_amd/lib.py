@@ -104,7 +104,13 @@ def load():
         _b.build()
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m czech_contriever_amd.build`")
-    lib = C.CDLL(LIB_PATH)
+    # CZC_LIB_VARIANT=<suffix>: kernel A/B on one device -- a second build of the SAME sources with other compile-time
+    # switches (python -m czech_contriever_amd.build --variant <suffix> -D...) sits beside the product as libczc_<suffix>.so
+    variant = os.environ.get("CZC_LIB_VARIANT")
+    path = LIB_PATH if not variant else os.path.join(os.path.dirname(LIB_PATH), f"libczc_{variant}.so")
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing (CZC_LIB_VARIANT={variant})")
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError = a symbol czc.h declares is not exported
         fn.restype, fn.argtypes = res, args
