@@ -72,6 +72,13 @@ if fetch is not None and write is not None:
         "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
         "algorithmic_bytes_per_launch": algo,
     }, open(os.path.join(prof, f"{tag}_pmc_ffn_up.json"), "w"), indent=1)
+    # the session's own bench line was printed before these passes existed for this binary: fill its traffic field from them
+    # (same session, same binary: the line's other figures are untouched)
+    if bench and bench["roofline"].get("traffic") is None:
+        bench["roofline"]["traffic"] = int((2 * fetch + write) * 1024)
+        bench["roofline"]["traffic_source"] = (f"rocprofv3 --pmc passes of this session (commit {commit}, gemm_bf16.hip sha1 {gemm_sha}), "
+                                               "filled in by tools/make_profiles.py")
+        json.dump(bench, open(os.path.join(prof, f"{tag}_bench_default.json"), "w"), indent=1)
 
 # 5. SQ counters per kernel over the bench (MFMA busy, waits) and over the attention driver
 for name, out in (("pmc_sq", f"{tag}_mfma_busy.csv"), ("pmc_attn", f"{tag}_pmc_attention.csv")):
