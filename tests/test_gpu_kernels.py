@@ -611,3 +611,26 @@ def test_gemm_two_weight_gradients_in_one_launch(ops, M1, M2, N, K, sp):
     assert torch.equal(out[:, :M1], r1) and torch.equal(out[:, M1:], r2)
     ref = torch.cat([a1.float().t() @ b1.float(), a2.float().t() @ b2.float()])
     report("pair", out.sum(0), ref, 2e-3 * math.sqrt(K), 1e-4)
+
+
+def test_gemm_output_store_policies_are_only_policies(ops):
+    """czc_gemm_set_tile + 512 / + 1024 / + 2048 (sc1 / nt / plain bf16 output stores; the default is nt from N = 2048 on):
+    a cache policy, nothing else -- every epilogue's outputs bit-identical, on a wide product with ragged edges."""
+    from czech_contriever_amd import lib as L
+    M, N, K = 700, 2312, 200
+    a, b, A, Bm = _mk(M, N, K, 0, 0, 71)
+    bias = rnd(N, seed=72)
+    aux = rnd(M, N, seed=73, dtype=BF16)
+    lib = L.load()
+    for epi, kw in [("store", {}), ("bias", dict(bias=bias)), ("add", dict(aux=aux)), ("dgelu", dict(aux=aux)),
+                    ("bias_gelu", dict(bias=bias)), ("bias_gelu_only", dict(bias=bias))]:
+        outs = []
+        for cfg in (0, 2048, 1024, 512):
+            L.check(lib.czc_gemm_set_tile(cfg))
+            try:
+                o = ops.gemm(A, Bm, epilogue=epi, **kw)
+            finally:
+                L.check(lib.czc_gemm_set_tile(0))
+            outs.append(torch.cat([x.reshape(-1) for x in o]) if isinstance(o, tuple) else o.reshape(-1))
+        for o in outs[1:]:
+            assert torch.equal(outs[0], o), epi
