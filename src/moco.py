@@ -126,7 +126,8 @@ class MoCo(nn.Module):
         for param_k in self.encoder_k.parameters():
             param_k.requires_grad = False
         # dropout streams pinned to the role, not to how many encoders the process built before (a teacher, a temporary
-        # Contriever): query encoder 0, key encoder 1; their position is checkpointed (src.utils.save, key "czc")
+        # Contriever): query encoder 0, key encoder 1; a resumed run is put at the checkpointed step's position by
+        # set_dropout_position (train.py), the checkpoint keeps the reference's five keys
         self.encoder_q.load_dropout_state({"salt": 0})
         self.encoder_k.load_dropout_state({"salt": 1})
 
