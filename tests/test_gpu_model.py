@@ -175,6 +175,36 @@ def test_encoder_other_widths_vs_oracle(gpu, shape_kw):
     assert float(torch.nn.functional.cosine_similarity(got, want, dim=0)) >= 1 - 3e-3
 
 
+@pytest.mark.parametrize("case", range(8))
+def test_encoder_random_shapes_vs_oracle(gpu, case):
+    """Seeded random encoder shapes between the pinned ones: width (a multiple of 64 up to 1024: the row kernels' chunk
+    counts and the GEMMs' ragged tiles), depth, intermediate size, batch, sequence length with ragged padding, pooling,
+    normalisation -- forward and all gradients against the oracle."""
+    import random
+    r = random.Random(9000 + case)
+    heads = r.choice([1, 2, 3, 5, 6, 9, 12, 13, 16])
+    H = 64 * heads
+    shape_kw = dict(vocab_size=r.choice([64, 512, 1000]), hidden_size=H, num_hidden_layers=r.choice([1, 2, 3]),
+                    num_attention_heads=heads, intermediate_size=64 * r.randrange(1, 24), max_position_embeddings=320)
+    pooling, norm = r.choice(["average", "cls"]), r.choice([False, True])
+    B, S = r.choice([1, 2, 5, 9]), r.choice([1, 7, 31, 32, 33, 64, 100, 129, 257, 300])
+    lengths = [S] + [r.randrange(1, S + 1) for _ in range(B - 1)]
+    enc, P, cfg_o = make_encoder(shape_kw, 9100 + case, pooling, gpu)
+    enc.eval()
+    ids, mask = ragged_batch(B, S, 9200 + case, shape_kw["vocab_size"], lengths)
+    Pg = {n: v.clone().requires_grad_(True) for n, v in P.items()}
+    ref = O.encoder_forward(Pg, ids, mask, cfg_o, pooling, norm)
+    emb = enc(input_ids=ids.to(gpu), attention_mask=mask.to(gpu), normalize=norm)
+    what = (shape_kw, pooling, norm, B, S, lengths)
+    assert float(cos_rows(emb.detach().cpu(), ref.detach()).min()) >= 1 - 1e-3, what
+    cot = O.det_uniform((B, H), 9300 + case)
+    (ref * cot).sum().backward()
+    (emb * cot.to(gpu)).sum().backward()
+    got = torch.cat([p.grad.reshape(-1) for p in enc.parameters()]).cpu().double()
+    want = torch.cat([Pg[n].grad.reshape(-1) for n, _ in O.param_names(cfg_o)]).double()
+    assert float(torch.nn.functional.cosine_similarity(got, want, dim=0)) >= 1 - 3e-3, what
+
+
 def _moco_opt(model_dir, **kw):
     d = dict(queue_size=64, momentum=0.99, temperature=0.05, label_smoothing=0.0, norm_doc=False, norm_query=False,
              moco_train_mode_encoder_k=False, weight_decay=0.01, weight_decay_from_init=False,
