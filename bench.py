@@ -470,7 +470,7 @@ def main():
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": None if kern_tflops is None else round(kern_tflops / PEAK_BF16_TFLOPS, 4),
                          "traffic": traffic,
-                         "kernel": "czc::gemm_kernel<0,0,2> FFN-up x.W1^T + bias -> (u, gelu(u)), "
+                         "kernel": "czc::gemm_kernel<0,0,2> FFN-up x.W1^T + bias -> (gelu'(u), gelu(u)), "
                                    f"M={M} N={N} K={K}, {2.0 * M * N * K / 1e9:.1f} GFLOP/launch",
                          "kernel_ms": round(kern_ms, 4), "launches_timed": cnt.value, "traffic_source": traffic_note,
                          "kernel_choice": "the largest single GEMM shape below its siblings' rate (FFN-up with its two-output "
