@@ -37,7 +37,7 @@ def _stale(target: str, deps) -> bool:
 
 
 def build_variant(suffix: str, defines, verbose: bool = True) -> str:
-    """A second library libczc_<suffix>.so from the same sources with extra -D switches (kernel A/B on one device:
+    """A second library libczc_<suffix>.so from the same sources with extra -D switches or compiler flags (kernel A/B on one device:
     CZC_LIB_VARIANT=<suffix> makes lib.load() take it).  Objects go to build_<suffix>/; nothing of the product build is touched."""
     obj = OBJ + "_" + suffix
     os.makedirs(obj, exist_ok=True)
@@ -98,6 +98,6 @@ def build(force: bool = False, verbose: bool = True) -> str:
 if __name__ == "__main__":
     if "--variant" in sys.argv:       # python -m czech_contriever_amd.build --variant nt -DATT_BWD_NT=1
         i = sys.argv.index("--variant")
-        print(build_variant(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith("-D")]))
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))    # -D switches and / or compiler flags (-mllvm X ...)
     else:
         print(build(force="--force" in sys.argv))
