@@ -904,6 +904,9 @@ static int launch_cfg(GemmArgs a, int splits, hipStream_t st) {
     CZC_HIP(hipGetDevice(&dev));
     CZC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     slots = cus * (160 * 1024 / CF::LDS);
+#ifdef CZC_SLOTS_OVERRIDE
+    slots = CZC_SLOTS_OVERRIDE;   // diagnostic builds: a persistent launch on part of the chip
+#endif
   }
   {
     const size_t ea = (AL == 0) ? (size_t)a.M * a.lda : (size_t)a.K * a.lda;   // elements spanned by A / B
