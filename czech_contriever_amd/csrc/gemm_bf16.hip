@@ -229,7 +229,25 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   constexpr int WNC = TN * 16;  // columns per wave
   constexpr int TILE_BYTES_A = CF::TILE_A, BUF_BYTES = CF::BUF;
 
-  const int split = blockIdx.y;
+  // Split-K launches (f32 slabs, one workgroup per (tile, split)): workgroups are dispatched round-robin over the 8 XCDs in
+  // linear order, so with split = blockIdx.y the 36 tiles of one split -- which share that split's K-range of BOTH
+  // operands -- were spread over all 8 L2s, and every L2 fetched nearly every panel (PMC: 1.43 GB from beyond L2 per
+  // weight-gradient launch against 0.50 GB of operands).  Here each XCD takes a contiguous run of the split-major
+  // (split, tile) list instead: an L2 sees one or two splits' panels, each tile row's A block and the B blocks once.
+  int split = blockIdx.y, tile0 = blockIdx.x;
+#ifdef CZC_NO_XCD_SPLIT   // A/B builds: the mapping before round 3's last change
+  const bool by_xcd = false;
+#else
+  const bool by_xcd = EPI == EPI_F32 && gridDim.y > 1;
+#endif
+  if (by_xcd) {
+    const int nt_ = a.tiles_m * a.tiles_n;
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x, nwg = gridDim.x * gridDim.y;
+    const int xcd = lin & 7, q = nwg >> 3, r = nwg & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    split = swz / nt_;
+    tile0 = swz - split * nt_;
+  }
   const int kt_total = (a.K + BK - 1) / BK;
   const int kt_begin = split * a.ktiles_per_split;
   int kt_end = kt_begin + a.ktiles_per_split;
@@ -244,7 +262,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   constexpr bool PREFETCH = (EPI != EPI_F32 && EPI != EPI_LSE && EPI != EPI_FILTER);
   const int ntiles = a.tiles_m * a.tiles_n;
   bool primed = false;   // K-tile 0 of the coming output tile was requested during the previous epilogue
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int tile = tile0; tile < ntiles; tile += gridDim.x) {
   // lane-derived addresses are recomputed per tile from an opaque copy of the thread id: hoisted out of the tile loop
   // they would stay live through the epilogue, where the accumulators, the prefetched second operand and the staged
   // segments already fill the register file (the hoisted form spilled ~100 dwords per lane and tile)
@@ -254,7 +272,8 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   int tm, tn;
-  swizzle_tile(tile, ntiles, a.tiles_m, a.tiles_n, a.group_n, tm, tn);
+  if (by_xcd) { tm = tile / a.tiles_n; tn = tile - tm * a.tiles_n; }   // row-major inside a split: a tile row's A block is shared by its column tiles
+  else swizzle_tile(tile, ntiles, a.tiles_m, a.tiles_n, a.group_n, tm, tn);
   const int row0 = tm * BM, col0 = tn * BN;
   // Two products in one launch (the f32 slab epilogue only; gemm_args.h): output rows from g_rows on are the SECOND
   // product's, with operands, leading dimensions and row count of their own (same N and K).  gA .. aM are what the
@@ -274,7 +293,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
     if (BL == 0) stage_kmajor<BN, CF::NW>(gB, gldb, c0, a.N, k0, a.K, tb, wave, lane);
     else         stage_mnmajor<BN, CF::NW>(gB, gldb, c0, a.N, k0, a.K, tb, wave, lane);
   };
-  if (!PREFETCH && tile != (int)blockIdx.x) __syncthreads();   // nobody still reads what the first DMA overwrites
+  if (!PREFETCH && tile != tile0) __syncthreads();   // nobody still reads what the first DMA overwrites
 
   f32x4 acc[TM][TN];
 #pragma unroll
