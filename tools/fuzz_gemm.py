@@ -44,7 +44,8 @@ def raw_gemm(A, Bm, al, bl, M, N, K, epi, bias, aux, splitk):
         out = torch.empty(M, N, dtype=BF16, device=dev)
     out2 = torch.empty(M, N, dtype=BF16, device=dev) if epi == "bias_gelu" else None
     p = lambda t: None if t is None else t.data_ptr()
-    L.check(lib.czc_gemm_bf16(al, bl, L.EPI[epi], M, N, K, p(A), A.stride(0), p(Bm), Bm.stride(0), p(out), N, p(bias), p(aux),
+    ld = lambda t: t.stride(0) if t.shape[0] > 1 else t.shape[1]      # (a one-row tensor reports an arbitrary stride)
+    L.check(lib.czc_gemm_bf16(al, bl, L.EPI[epi], M, N, K, p(A), ld(A), p(Bm), ld(Bm), p(out), N, p(bias), p(aux),
                               p(out2), splitk, L.stream_ptr()))
     return (out, out2) if epi == "bias_gelu" else out
 
