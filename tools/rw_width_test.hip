@@ -103,5 +103,13 @@ int main() {
     }
     CASE(3, 2) CASE(2, 1) CASE(1, 1) CASE(3, 0) CASE(0, 2)
   }
+  // one CU's own store / load path: a few workgroups on an otherwise idle chip (4 waves each; 16 waves = one full CU's worth
+  // when they land on one CU -- the dispatcher spreads workgroups, so read "per workgroup")
+  for (int grid : {1, 2, 4, 8}) {
+    const int r = 8192;
+    const double tw = run<1, 0, 1>(din, dout, r, grid), tr = run<1, 1, 0>(din, dout, r, grid), tw8 = run<0, 0, 1>(din, dout, r, grid);
+    printf("grid %d (chip idle)  write-only 16+8 B: %7.1f us = %5.1f GB/s per workgroup; 8 B pieces: %5.1f GB/s; read-only: %5.1f GB/s per workgroup\n", grid, tw,
+           r * 1536.0 / tw / 1e3 / grid, r * 1536.0 / tw8 / 1e3 / grid, r * 1536.0 / tr / 1e3 / grid);
+  }
   return 0;
 }
