@@ -361,6 +361,37 @@ def test_gemm_workgroups_walking_over_tiles(ops, al, bl):
             report("walk add", outs[0], acc.to(BF16).float() + aux.float(), 5e-2, 8e-3)
 
 
+def test_gemm_operands_beyond_two_gib(ops):
+    """An operand that spans 2 GiB and more leaves the scalar-base / 32-bit-offset addressing of the DMA pieces (`fast_addr`,
+    gemm_bf16.hip) for the per-lane 64-bit pointers: the ping-pong K-loop's slow staging, the plain loop's, and the
+    transposing-read kernel's, each against fp32 rows of the reference; and a bf16 output a buffer descriptor cannot address
+    (4 GiB) is refused before any launch."""
+    from czech_contriever_amd import lib as L
+    M, N, K = 70016, 256, 16384                       # A: 70016 x 16384 bf16 = 2.29 GB
+    g = torch.Generator(device=dev()).manual_seed(91)  # (drawn on the device: 1.1 G values)
+    a = (torch.randn(M, K, device=dev(), generator=g) * 0.25).to(BF16)
+    b = (torch.randn(N, K, device=dev(), generator=g) * 0.25).to(BF16)
+    assert a.numel() * 2 > (1 << 31)
+    rows = torch.tensor([0, 1, 255, 256, 40000, 65535, 65536, M - 1], device=dev())
+    ref = a[rows].float() @ b.float().t()
+    lib = L.load()
+    for cfg in (0, 65):                               # ping-pong (K >= 1536) and the plain K-loop
+        L.check(lib.czc_gemm_set_tile(cfg))
+        try:
+            c = ops.gemm(a, b)
+        finally:
+            L.check(lib.czc_gemm_set_tile(0))
+        report(f"gemm beyond 2 GiB cfg {cfg}", c[rows], ref, 0.02 * math.sqrt(K) * 0.0625 + 2e-2, 8e-3)
+    at = a.t().contiguous()                           # [K, M]: the M-major operand of the weight-gradient products
+    del a
+    bt = b.t().contiguous()
+    slabs = ops.gemm(at, bt, a_layout=1, b_layout=1, epilogue="f32", M=M, N=N, K=K, splitk=2)
+    report("gemm beyond 2 GiB, transposing reads", slabs.sum(0)[rows], ref, 2e-3 * math.sqrt(K) * 0.0625 + 1e-3, 1e-4)
+    # M x ldc x 2 bytes >= 4 GiB: refused on the arguments alone (the pointers are never touched)
+    rc = lib.czc_gemm_bf16(0, 0, 0, 70016, 256, 64, L.ptr(bt), 64, L.ptr(bt), 64, L.ptr(c), 32768, None, None, None, 1, L.stream_ptr())
+    assert rc != 0 and b"4 GiB" in lib.czc_last_error()
+
+
 def test_gemm_splitk_weight_gradient(ops):
     # dW[N',K'] = dY^T X, reduction over 3000 tokens, split 7 ways, then the slab reduction
     Mtok, No, Ko = 3000, 768, 384
