@@ -281,6 +281,18 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_res_kernel(const AttnArgs a) 
   const int r = lane & 31, h = lane >> 5;
   const int spad = (S + 31) & ~31;
   const bool active = q0 < S;  // wave-uniform
+#ifdef ATTF_STAMPS   // diagnostic build only (tools/stamp_attn_fwd.py): s_memtime of wave ATTF_STAMPS / lane 0 and where the workgroup
+                     // runs (HW_ID, XCC_ID) into the workgroup's lse row; lse itself is not written in such a build
+  long long* stamp_buf = (long long*)(a.lse + ((size_t)b * a.nh + hh) * S);
+#define ATTF_STAMP(k) do { if (wave == ATTF_STAMPS && lane == 0) { stamp_buf[k] = __builtin_amdgcn_s_memtime(); if ((k) == 0 || (k) == 6) stamp_buf[8 + ((k) != 0)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+  if (wave == ATTF_STAMPS && lane == 0) {
+    stamp_buf[10] = __builtin_amdgcn_s_getreg(0xF804);
+    stamp_buf[11] = __builtin_amdgcn_s_getreg(0xF814);
+  }
+#else
+#define ATTF_STAMP(k) do { } while (0)
+#endif
+  ATTF_STAMP(0);
   const float c2 = 0.125f * LOG2E;
   const bf16_t* base = a.qkv + (size_t)b * S * H3 + hh * 64;
 
@@ -312,6 +324,11 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_res_kernel(const AttnArgs a) 
   }
   const bool kvalid = tid < S && a.mask[(size_t)b * S + (tid < S ? tid : 0)];
   __builtin_amdgcn_sched_barrier(0);
+  ATTF_STAMP(1);
+#ifdef ATTF_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ATTF_STAMP(2);
+#endif
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int id = tid + 512 * i, row = id >> 3, c = id & 7;
@@ -327,6 +344,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_res_kernel(const AttnArgs a) 
     }
   }
   __syncthreads();
+  ATTF_STAMP(3);
   if (!active) return;
 
   f32x16 o[2];
@@ -429,6 +447,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_res_kernel(const AttnArgs a) 
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, k0 + 16 * s2, 32 * dt, lane), pf, o[dt], 0, 0, 0);
     }
   }
+  ATTF_STAMP(4);
   l = xor32_sum(l);
   const float inv = (DROP ? a.inv_keep : 1.0f) / l;
   const int q = q0 + r;
@@ -448,8 +467,15 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_res_kernel(const AttnArgs a) 
         asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ay), "+v"(by));
         if (q < S) *(uint4*)(dst + 32 * dt + 8 * g) = make_uint4(ax, ay, bx, by);
       }
+#ifndef ATTF_STAMPS
     if (q < S && h == 0) a.lse[((size_t)b * a.nh + hh) * S + q] = (m + __log2f(l)) * LN2;
+#endif
   }
+  ATTF_STAMP(5);
+#ifdef ATTF_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ATTF_STAMP(6);
+#endif
   if (DROP && KEEP) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::: "memory");   // the scalar stores sit in the scalar cache until written back
 }
 
