@@ -47,5 +47,3 @@ for n, v in zip(names, d):
     print(f"  {n:28s} {statistics.median(v):8.0f} {v[len(v)//10]:8.0f} {v[9*len(v)//10]:8.0f}")
 tot = sorted((st[w, 6] - st[w, 0]).item() for w in range(B * nh))
 print(f"  {'workgroup total':28s} {statistics.median(tot):8.0f} {tot[len(tot)//10]:8.0f} {tot[9*len(tot)//10]:8.0f}   = {statistics.median(tot)/clk/1e3:.1f} us")
-t0 = min(st[w, 0].item() for w in range(B * nh)); t1 = max(st[w, 6].item() for w in range(B * nh))
-print(f"  launch span {(t1 - t0)/clk/1e3:.1f} us; workgroups {B*nh}: {B*nh*statistics.median(tot)/(t1-t0):.1f} resident on average ({B*nh*statistics.median(tot)/(t1-t0)/256:.2f} per CU)")
