@@ -72,6 +72,85 @@ def test_train_cli_runs_saves_and_resumes(tmp_path, monkeypatch):
     assert torch.equal(enc.state_dict()["encoder.layer.0.output.dense.weight"], w6)
 
 
+def test_resumed_run_follows_the_uninterrupted_trajectory(tmp_path):
+    """Dropout ON: six optimizer steps in one go against three steps, utils.save, utils.load into fresh objects,
+    set_dropout_position and three more.  Everything a step depends on must survive the checkpoint: both encoders, the
+    queue and its pointer, the Adam moments and step count, the schedule, and the position of the two dropout streams.
+    The two runs may differ by the float atomics' last bits only (embedding / LayerNorm / bias gradients: DESIGN.md section
+    4 (9)), which two uninterrupted runs differ by as well -- measured here as the yardstick; a replayed or shifted dropout
+    stream, a lost moment or a reset schedule moves most weights by ~lr per step."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from src import moco, utils
+    mdir = _cfg_dir(tmp_path)                      # TINY with its default dropout 0.1 / 0.1
+    dev = torch.device("cuda:0")
+
+    def opts():
+        return types.SimpleNamespace(
+            queue_size=64, momentum=0.99, temperature=0.05, label_smoothing=0.1, norm_doc=True, norm_query=True,
+            moco_train_mode_encoder_k=False, weight_decay=0.01, weight_decay_from_init=False, retriever_model_id=mdir,
+            pooling="average", random_init=True, projection_size=128, optim="adamw", lr=1e-3, beta1=0.9, beta2=0.98,
+            eps=1e-6, warmup_steps=2, total_steps=8, lr_min_ratio=0.0, scheduler="linear", seed=0)
+
+    def batch(i):
+        qt, qm = ragged_batch(8, 24, 8300 + i, 512, [24, 17, 3, 24, 9, 24, 12, 20])
+        kt, km = ragged_batch(8, 24, 8400 + i, 512, [20, 24, 5, 11, 24, 7, 24, 16])
+        return qt.to(dev), qm.to(dev), kt.to(dev), km.to(dev)
+
+    def fresh():
+        torch.manual_seed(0)
+        opt = opts()
+        model = moco.MoCo(opt)
+        P = O.make_params(O.BertShape(**TINY), 71)
+        model.encoder_q.load_state_dict(P)
+        model.encoder_k.load_state_dict(P)
+        with torch.no_grad():
+            model.queue.copy_(torch.nn.functional.normalize(O.det_uniform((128, 64), 72), dim=0))
+        model = model.to(dev).train()
+        optimizer, scheduler = utils.set_optim(opt, model)
+        return opt, model, optimizer, scheduler
+
+    def steps(model, optimizer, scheduler, lo, hi):
+        for i in range(lo, hi):
+            loss, _ = model(*batch(i), stats_prefix="train")
+            loss.backward()
+            optimizer.step()
+            scheduler.step()
+            model.zero_grad()
+
+    def state(model, optimizer):
+        torch.cuda.synchronize()
+        sd = optimizer.state_dict()["state"]
+        return (model.encoder_q.flat_params.cpu().clone(), model.encoder_k.flat_params.cpu().clone(), model.queue.cpu().clone(),
+                int(model.queue_ptr), torch.cat([sd[k]["exp_avg"].reshape(-1).cpu() for k in sorted(sd)]))
+
+    runs = []
+    for _ in range(2):                              # two uninterrupted runs: the yardstick
+        opt, model, optimizer, scheduler = fresh()
+        steps(model, optimizer, scheduler, 0, 6)
+        runs.append(state(model, optimizer))
+    opt, model, optimizer, scheduler = fresh()
+    steps(model, optimizer, scheduler, 0, 3)
+    utils.save(model, optimizer, scheduler, 3, opt, str(tmp_path), "step-3")
+    del model, optimizer, scheduler
+    torch.manual_seed(0)                            # (train.py seeds before it builds or loads anything)
+    model, optimizer, scheduler, opt2, step = utils.load(moco.MoCo, os.path.join(str(tmp_path), "checkpoint", "step-3"), opts())
+    assert step == 3
+    model.train()
+    model.set_dropout_position(step * 1)            # train.py: step * update_freq micro-steps
+    steps(model, optimizer, scheduler, 3, 6)
+    resumed = state(model, optimizer)
+
+    assert resumed[3] == runs[0][3] == runs[1][3]
+    for idx, name in ((0, "query weights"), (1, "key weights"), (2, "queue"), (4, "first moments")):
+        noise = (runs[0][idx] - runs[1][idx]).abs()
+        d = (resumed[idx] - runs[0][idx]).abs()
+        scale = float(runs[0][idx].abs().max())
+        # within a few times what two uninterrupted runs differ by (floor: 1e-6 of the tensor's scale, for runs that agree bit for bit)
+        assert float(d.mean()) <= 4.0 * float(noise.mean()) + 1e-6 * scale, (name, float(d.mean()), float(noise.mean()))
+        assert float(d.max()) <= 4.0 * float(noise.max()) + 2e-3 * scale, (name, float(d.max()), float(noise.max()))
+
+
 def test_train_cli_inbatch_mode(tmp_path, monkeypatch):
     """--contrastive_mode inbatch (reference train.py:451-452) through the same loop: checkpoint keys are `encoder.*`."""
     if not torch.cuda.is_available():
