@@ -89,4 +89,31 @@ for name, out in (("pmc_sq", f"{tag}_mfma_busy.csv"), ("pmc_attn", f"{tag}_pmc_a
             with open(os.path.join(prof, out), "w") as f:
                 f.write(r.stdout)
                 f.write(f"# rocprofv3 --pmc <SQ counters> GRBM_GUI_ACTIVE --kernel-trace; per-dispatch values averaged per kernel; quad-cycle counters (SQ_WAVE_CYCLES, SQ_WAIT_*) as reported; commit {commit}\n")
+# 6. beyond-L2 traffic of EVERY kernel of a step (the same two --pmc passes): launches per step, corrected FETCH and WRITE
+#    per launch, distinct per-launch values where a kernel runs several shapes
+def per_kernel(dirname, counter, scale):
+    import collections, re
+    out = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(src, dirname, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                out[re.sub(r"\(.*", "", r["Kernel_Name"])].append(float(r["Counter_Value"]) * scale * 1024 / 1e6)
+    return out
+F, W = per_kernel("pmc_fetch", "FETCH_SIZE", 2.0), per_kernel("pmc_write", "WRITE_SIZE", 1.0)
+if F:
+    steps = 3   # bench.py --steps 2 --warmup 1
+    rows = []
+    for k in F:
+        f_, w_ = F[k], W.get(k, [0.0])
+        rows.append((sum(f_) + sum(w_), k, len(f_) / steps, sum(f_) / len(f_), sum(w_) / max(1, len(w_)),
+                     " ".join(str(v) for v in sorted(set(round(x) for x in f_))[:6])))
+    rows.sort(reverse=True)
+    with open(os.path.join(prof, f"{tag}_traffic_kernels.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "launches_per_step", "fetch_MB_per_launch", "write_MB_per_launch", "GB_per_step", "distinct_fetch_MB"])
+        for tot, k, n, fm, wm, dist in rows:
+            if tot / steps < 1.0:
+                continue
+            w.writerow([k.strip(), round(n, 2), round(fm, 1), round(wm, 1), round(tot / steps / 1e3, 2), dist])
+        w.writerow([f"# total {sum(r[0] for r in rows) / steps / 1e3:.1f} GB per step; rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) over bench.py --steps 2 --warmup 1; FETCH_SIZE doubled (gfx950: 64 B counted per 128-B request); L2 misses, i.e. traffic from the Infinity Cache and HBM together; commit {commit}"])
 print("profiles written for commit", commit)
