@@ -74,6 +74,12 @@ __device__ __forceinline__ void glds16_pin(const void* src, lptr_t dst, PIN& pin
   const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)dst);
   asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off" : "+v"(pin), "+v"(after) : "v"(src), "s"(l) : "memory", "m0");
 }
+// the same as a streaming (nt) read (gemm_kernel<..., ANT>: the A rows of a long-K product with three column tiles)
+template <class PIN, class AFTER>
+__device__ __forceinline__ void glds16_pin_nt(const void* src, lptr_t dst, PIN& pin, AFTER& after) {
+  const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)dst);
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off nt" : "+v"(pin), "+v"(after) : "v"(src), "s"(l) : "memory", "m0");
+}
 // The same from a wave-uniform 64-bit base (SGPRs) plus a 32-bit per-lane byte offset: the offsets of a workgroup's
 // DMA pieces do not change along K, only the base does, so the K-loop spends scalar adds instead of ~13 vector
 // instructions per piece on addresses (stamps: the eight pieces after the barrier took a wave 650-1250 cycles of a
@@ -222,7 +228,13 @@ __device__ __forceinline__ void store16(u32x4_st v, __amdgpu_buffer_rsrc_t rc, u
   else __builtin_amdgcn_raw_buffer_store_b128(v, rc, off, 0, 0);
 }
 
-template <int AL, int BL, int EPI, class CF, bool PP = false>
+// ANT (with PP, K-major operands): the A operand's full interior K-tiles are requested as streaming (nt) reads.  For the
+// long-K products with three column tiles (FFN-down, the input-gradient products): their A rows (402 / 302 MB) are read
+// once per launch and shared by three workgroups only; read with the default policy they push out of the Infinity Cache
+// what the kernels behind them read next (the residual stream's rows).  A compile-time parameter: a wave-uniform branch
+// per DMA piece cost every ping-pong product 2-3 %, and on the wide K = 768 products nt evicts rows that 9-12 column tiles
+// share.
+template <int AL, int BL, int EPI, class CF, bool PP = false, bool ANT = false>
 __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BM = CF::BM, BN = CF::BN, TM = CF::TM, TN = CF::TN, WN = CF::WN;
@@ -445,6 +457,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
         const char* base = (const char*)gA + ((AL == 0) ? (size_t)k0 * 2 : (size_t)k0 * glda * 2);
         lptr_t dst = (lptr_t)(smem + (t & 1) * BUF_BYTES + q * 1024);
         if (AL == 1 && BL == 1) glds16_sbase(poff_a[2 * h + i], base, dst, np, np2);
+        else if (ANT) glds16_pin_nt(base + poff_a[2 * h + i], dst, np, np2);
         else glds16_pin(base + poff_a[2 * h + i], dst, np, np2);
       } else {
         const char* base = (const char*)gB + ((BL == 0) ? (size_t)k0 * 2 : (size_t)k0 * gldb * 2);
@@ -901,10 +914,10 @@ static bool g_one_wg_per_tile = false;
 static int g_pingpong = 0;             // 0 = built-in choice; tuning knob czc_gemm_set_tile: +32 = always, +64 = never  // tuning knob: switch the persistent tile loop off
 
 static int g_store_pol = -1;   // -1 = built-in choice; czc_gemm_set_tile +512: sc1 output stores, +1024: nt, +2048: plain
-template <int AL, int BL, int EPI, class CF, bool PP = false>
+template <int AL, int BL, int EPI, class CF, bool PP = false, bool ANT = false>
 static int launch_cfg(GemmArgs a, int splits, hipStream_t st) {
   static bool attr_done = false;
-  auto kern = gemm_kernel<AL, BL, EPI, CF, PP>;
+  auto kern = gemm_kernel<AL, BL, EPI, CF, PP, ANT>;
   if (!attr_done) {
     CZC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS));
     attr_done = true;
@@ -958,7 +971,14 @@ static int launch(const GemmArgs& a, int splits, hipStream_t st) {
   // K-major x K-major products with a long K or a wide N (FFN-up / FFN-down / QKV forward: -1..-5 %); it loses on
   // the transposing-read kernels (their LOAD slots are twice as long) and on the 768 x 768 projections
   const bool pp_auto = (AL == 0 && BL == 0 && splits == 1 && (a.K >= 1536 || a.N >= 2304));
-  if (g_pingpong == 1 || (g_pingpong == 0 && pp_auto)) return launch_cfg<AL, BL, EPI, CfgBig, true>(a, splits, st);
+  if (g_pingpong == 1 || (g_pingpong == 0 && pp_auto)) {
+#ifndef CZC_NO_ANT
+    if constexpr (AL == 0 && BL == 0 && (EPI == EPI_BIAS || EPI == EPI_ADD)) {
+      if (a.K >= 1536 && a.N <= 1024) return launch_cfg<AL, BL, EPI, CfgBig, true, true>(a, splits, st);
+    }
+#endif
+    return launch_cfg<AL, BL, EPI, CfgBig, true>(a, splits, st);
+  }
   return launch_cfg<AL, BL, EPI, CfgBig>(a, splits, st);
 }
 
