@@ -290,7 +290,13 @@ class FlatBertEncoder(nn.Module):
             self._scratch = torch.empty(n, dtype=torch.uint8, device=self._flat.device)
         return self._scratch
 
-    # ---- dropout stream position (checkpointed by src.utils.save / restored by src.utils.load) ----
+    # ---- dropout stream position.  NOT in the checkpoint (it keeps the reference's five keys): train.py / distill.py put a
+    # resumed run at step * update_freq (set_dropout_position), derived from the CURRENT options ----
+    def dropout_seed(self, calls=None) -> int:
+        """Seed of this encoder's `calls`-th training forward (default: the next one): (--seed, role salt, position)."""
+        calls = self._drop_calls + 1 if calls is None else int(calls)
+        return (torch.initial_seed() * 2654435761 + calls * 40503 + (self._salt + 1) * 0x9E3779B1) & 0xFFFFFFFF
+
     def dropout_state(self) -> dict:
         return {"salt": int(self._salt), "calls": int(self._drop_calls)}
 
@@ -333,9 +339,9 @@ class FlatBertEncoder(nn.Module):
             self._drop_calls += 1
         ws = self._lease_activations(B, S, self._call) if save else self._workspace(B, S, False)
         emb = torch.empty(B, self.config.hidden_size, dtype=F32, device=ids.device)
-        # (--seed, encoder, training forward): the same run draws the same masks, a resumed run continues the stream
-        # (dropout_state() travels in the checkpoint); query and key encoder never share a stream of draws
-        seed = (torch.initial_seed() * 2654435761 + self._drop_calls * 40503 + (self._salt + 1) * 0x9E3779B1) & 0xFFFFFFFF
+        # (--seed, encoder, training forward): the same run draws the same masks, a resumed run is put at the position
+        # step * update_freq by its script; query and key encoder never share a stream of draws
+        seed = self.dropout_seed(self._drop_calls)
         n_split, ev = (0, None) if (split is None or save) else (int(split[0]), split[1])
         L.check(L.load().czc_encoder_forward(
             C.byref(self._shape), self._flat.data_ptr(), self.mirror().data_ptr(), ids.data_ptr(), mask.data_ptr(),

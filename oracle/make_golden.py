@@ -361,6 +361,157 @@ def g_distill():
     save("g13_distill.npz", **out)
 
 
+class GivenDropout:
+    """Within the block, torch.nn.functional.dropout(x, p, training=True) is x * (the next scale of `scales`): the
+    reference's modules (HF BertEmbeddings / BertSelfOutput / BertOutput via nn.Dropout, eager_attention_forward) then run
+    their TRAINING-mode arithmetic under a dropout outcome that is given instead of drawn.  torch is patched, not the
+    reference; call order per encoder pass: embeddings, then per layer attention probabilities, attention output, FFN
+    output (checked by shape)."""
+
+    def __init__(self, scales):
+        self.scales = list(scales)
+        self.i = 0
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self._orig = F.dropout
+
+        def given(x, p=0.5, training=True, inplace=False):
+            assert training and p > 0, (p, training)
+            sc = self.scales[self.i]
+            assert tuple(sc.shape) == tuple(x.shape), (self.i, tuple(sc.shape), tuple(x.shape))
+            self.i += 1
+            return x * sc
+
+        F.dropout = given
+        return self
+
+    def __exit__(self, *exc):
+        import torch.nn.functional as F
+        F.dropout = self._orig
+        if exc[0] is None:
+            assert self.i == len(self.scales), (self.i, len(self.scales))
+
+
+def scales_in_call_order(masks, cfg):
+    out = [masks["emb"]]
+    for l in range(cfg.num_hidden_layers):
+        out += [masks[("attn", l)], masks[("h1", l)], masks[("h2", l)]]
+    return out
+
+
+def train_encoder(rc, cfg, P, pooling):
+    enc = ref_encoder(rc, cfg, P, pooling)
+    enc.config._attn_implementation = "eager"   # the sdpa path draws its dropout inside the fused op: same arithmetic, not patchable
+    enc.train()                                 # train.py:246 model.train(): dropout 0.1 / 0.1 on
+    return enc
+
+
+def g_train_masks(rc, rm, ru):
+    """g15: the reference in TRAINING mode (dropout on: train.py:246, src/moco.py:306-321) under dropout outcomes taken
+    from the kernels' counter RNG (tests/dropout_ref.py restates it in numpy; the fixture stores seeds, not masks):
+      tiny_*   tiny encoder, ragged batch: embeddings + every parameter gradient of sum(emb * cot)
+      base_*   bert-base-width layer, S 256 ragged: embeddings + subsampled gradients (as g12)
+      split*_  key-encoder style no_grad pass whose last layer ran in two batch ranges (czc_encoder_forward split_batch)
+      moco_*   3 MoCo micro-steps with BOTH encoders in train mode (query seeds salt 0, key seeds salt 1)"""
+    from tests import dropout_ref as D
+    out = {}
+    # ---- tiny encoder
+    cfg = O.BertShape(**TINY)
+    seed, B, S, dseed = 11, 5, 24, D.engine_seed(90001, 1, 0)   # = the engine's first training forward under torch.manual_seed(90001), salt 0
+    P = O.make_params(cfg, seed)
+    ids, mask = ragged_batch(B, S, seed + 1, cfg.vocab_size, [24, 17, 1, 9, 24])
+    cot = O.det_uniform((B, cfg.hidden_size), seed + 2)
+    out.update(tiny_ids=ids, tiny_mask=mask, tiny_seed=seed, tiny_cot=cot, tiny_dseed=dseed)
+    masks = D.encoder_scales(dseed, cfg, B, S)
+    for pooling, norm in (("average", False), ("average", True), ("cls", False)):
+        enc = train_encoder(rc, cfg, P, pooling)
+        with GivenDropout(scales_in_call_order(masks, cfg)):
+            emb = enc(input_ids=ids, attention_mask=mask, normalize=norm)
+        (emb * cot).sum().backward()
+        tag = f"{pooling}_{int(norm)}"
+        out[f"tiny_emb_{tag}"] = emb.detach()
+        for n, p in enc.named_parameters():
+            out[f"tiny_grad_{tag}::{n}"] = p.grad
+    # ---- bert-base width
+    cfg = O.BertShape(**BASE1)
+    seed, B, S, dseed = 23, 4, 256, D.engine_seed(90002, 1, 0)
+    P = O.make_params(cfg, seed)
+    ids, mask = ragged_batch(B, S, seed + 1, cfg.vocab_size, [256, 130, 27, 201])
+    cot = O.det_uniform((B, cfg.hidden_size), seed + 2)
+    out.update(base_ids=ids, base_mask=mask, base_seed=seed, base_cot=cot, base_dseed=dseed)
+    masks = D.encoder_scales(dseed, cfg, B, S)
+    for pooling, norm in (("average", False), ("average", True)):
+        enc = train_encoder(rc, cfg, P, pooling)
+        with GivenDropout(scales_in_call_order(masks, cfg)):
+            emb = enc(input_ids=ids, attention_mask=mask, normalize=norm)
+        (emb * cot).sum().backward()
+        tag = f"{pooling}_{int(norm)}"
+        out[f"base_emb_{tag}"] = emb.detach()
+        for n, p in enc.named_parameters():
+            g = p.grad.reshape(-1)
+            stride = max(1, (g.numel() + 4095) // 4096)
+            out[f"base_grad_{tag}::{n}"] = g[::stride].clone()
+            out[f"base_gstat_{tag}::{n}"] = np.array([float(g.double().sum()), float(g.double().norm()), float(stride)])
+    # ---- the last layer in two batch ranges (tiny, 2 layers; and the base-width single layer)
+    for tag, shape_kw, seed, B, S, lengths, split, dseed in (
+            ("split3", TINY, 13, 8, 24, [24, 17, 1, 9, 24, 20, 3, 24], 3, D.engine_seed(90003, 1, 1)),   # salt 1: the key encoder
+            ("split2b", BASE1, 25, 4, 256, [256, 130, 27, 201], 2, D.engine_seed(90004, 1, 1))):
+        cfg = O.BertShape(**shape_kw)
+        P = O.make_params(cfg, seed)
+        ids, mask = ragged_batch(B, S, seed + 1, cfg.vocab_size, lengths)
+        masks = D.encoder_scales(dseed, cfg, B, S, split=split)
+        enc = train_encoder(rc, cfg, P, "average")
+        with torch.no_grad(), GivenDropout(scales_in_call_order(masks, cfg)):
+            emb = enc(input_ids=ids, attention_mask=mask, normalize=False)
+        out.update({f"{tag}_ids": ids, f"{tag}_mask": mask, f"{tag}_seed": seed, f"{tag}_dseed": dseed,
+                    f"{tag}_split": split, f"{tag}_emb": emb})
+    # ---- MoCo micro-steps, both encoders in train mode
+    cfg = O.BertShape(**TINY)
+    P = O.make_params(cfg, 71)
+    C, K, B, S, init_seed = cfg.hidden_size, 64, 8, 24, 4242
+    m = bare_moco(rm)
+    m.momentum, m.temperature, m.label_smoothing = 0.99, 0.05, 0.1   # g9's flags: normalised embeddings, every step has a real gradient
+    m.encoder_q = train_encoder(rc, cfg, P, "average")
+    m.encoder_k = train_encoder(rc, cfg, P, "average")
+    for p in m.encoder_k.parameters():
+        p.requires_grad = False
+    m.register_buffer("queue", torch.nn.functional.normalize(O.det_uniform((C, K), 72), dim=0))
+    m.register_buffer("queue_ptr", torch.zeros(1, dtype=torch.long))
+    m.queue_size = K
+    enq = rm.MoCoDistill._dequeue_and_enqueue
+    opt = types.SimpleNamespace(optim="adamw", weight_decay_from_init=False, lr=1e-3, beta1=0.9, beta2=0.98,
+                                eps=1e-6, weight_decay=0.01, warmup_steps=2, total_steps=10, lr_min_ratio=0.0,
+                                scheduler="linear")
+    optimizer, scheduler = ru.set_optim(opt, m)
+    losses, qs, ks = [], [], []
+    for step in range(3):
+        lens_q = [S, 17, 3, 24, 9, 24, 12, 20]
+        lens_k = [20, S, 5, 11, 24, 7, 24, 16]
+        q_tokens, q_mask = ragged_batch(B, S, 7300 + step, cfg.vocab_size, lens_q)
+        k_tokens, k_mask = ragged_batch(B, S, 7400 + step, cfg.vocab_size, lens_k)
+        qm = D.encoder_scales(D.engine_seed(init_seed, step + 1, 0), cfg, B, S)
+        km = D.encoder_scales(D.engine_seed(init_seed, step + 1, 1), cfg, B, S)
+        with GivenDropout(scales_in_call_order(qm, cfg) + scales_in_call_order(km, cfg)):
+            q = m.encoder_q(input_ids=q_tokens, attention_mask=q_mask, normalize=True)
+            with torch.no_grad():
+                m._momentum_update_key_encoder()
+                k = m.encoder_k(input_ids=k_tokens, attention_mask=k_mask, normalize=True)
+        logits = m._compute_logits(q, k) / m.temperature
+        loss = torch.nn.functional.cross_entropy(logits, torch.zeros(B, dtype=torch.long), label_smoothing=m.label_smoothing)
+        enq(m, k, None)
+        loss.backward()
+        optimizer.step()
+        scheduler.step()
+        m.zero_grad()
+        losses.append(float(loss)); qs.append(q.detach().clone()); ks.append(k.detach().clone())
+    out.update(moco_init_seed=init_seed, moco_losses=np.array(losses), moco_q=torch.stack(qs), moco_k=torch.stack(ks),
+               moco_queue_final=m.queue,
+               moco_wq_probe=m.encoder_q.state_dict()["encoder.layer.1.output.dense.weight"][::7, ::5],
+               moco_wk_probe=m.encoder_k.state_dict()["encoder.layer.1.output.dense.weight"][::7, ::5])
+    save("g15_train_masks.npz", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -384,6 +535,7 @@ def main():
         "g10": lambda: g_inbatch(rc, ri),
         "g12": lambda: g_base_grads(rc),
         "g13": lambda: g_distill(),
+        "g15": lambda: g_train_masks(rc, rm, ru),
     }
     for k, fn in jobs.items():
         if a.only and k not in a.only.split(","):

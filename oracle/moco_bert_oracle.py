@@ -155,11 +155,22 @@ def make_params(cfg: BertShape, seed: int, scale: float = 0.02 * math.sqrt(3.0))
 # --------------------------------------------------------------------------------------
 # encoder
 # --------------------------------------------------------------------------------------
-def _dropout(x, p, training):
+def _dropout(x, p, training, scale=None):
+    """torch.nn.Dropout in training mode is x * keep / (1 - p) with keep ~ Bernoulli(1 - p) (HF BertEmbeddings /
+    BertSelfOutput / BertOutput `self.dropout`, eager_attention_forward's `nn.functional.dropout`).  torch's own draws
+    cannot be reproduced outside torch, so a caller that wants a GIVEN outcome hands the multiplicative `scale`
+    (= keep / (1 - p)) in: pinned by g15, where the reference's modules run in train() mode with
+    torch.nn.functional.dropout replaced by the same multiplication (oracle/make_golden.py:g_train_masks)."""
+    if scale is not None:
+        return x * scale
     return F.dropout(x, p=p, training=training) if (training and p > 0.0) else x
 
 
-def embeddings(P, ids, cfg: BertShape, training=False):
+def _m(masks, key):
+    return None if masks is None else masks.get(key)
+
+
+def embeddings(P, ids, cfg: BertShape, training=False, masks=None):
     B, S = ids.shape
     x = P["embeddings.word_embeddings.weight"][ids]
     x = x + P["embeddings.token_type_embeddings.weight"][0][None, None, :]
@@ -167,10 +178,10 @@ def embeddings(P, ids, cfg: BertShape, training=False):
     x = F.layer_norm(
         x, (cfg.hidden_size,), P["embeddings.LayerNorm.weight"], P["embeddings.LayerNorm.bias"], cfg.layer_norm_eps
     )
-    return _dropout(x, cfg.hidden_dropout_prob, training)
+    return _dropout(x, cfg.hidden_dropout_prob, training, _m(masks, "emb"))
 
 
-def self_attention(P, pre, x, key_mask, cfg: BertShape, training=False):
+def self_attention(P, pre, x, key_mask, cfg: BertShape, training=False, pscale=None):
     B, S, H = x.shape
     nh, d = cfg.num_attention_heads, cfg.head_dim
 
@@ -184,7 +195,7 @@ def self_attention(P, pre, x, key_mask, cfg: BertShape, training=False):
     bias = torch.zeros(B, 1, 1, S, dtype=x.dtype)
     bias = bias.masked_fill(~key_mask[:, None, None, :].bool(), torch.finfo(x.dtype).min)
     probs = torch.softmax(scores + bias, dim=-1)
-    probs = _dropout(probs, cfg.attention_probs_dropout_prob, training)
+    probs = _dropout(probs, cfg.attention_probs_dropout_prob, training, pscale)
     ctx = (probs @ v).transpose(1, 2).reshape(B, S, H)
     return ctx
 
@@ -193,12 +204,12 @@ def gelu_erf(x):
     return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
 
 
-def encoder_layer(P, l, x, key_mask, cfg: BertShape, training=False):
+def encoder_layer(P, l, x, key_mask, cfg: BertShape, training=False, masks=None):
     pre = f"encoder.layer.{l}."
     H = cfg.hidden_size
-    ctx = self_attention(P, pre, x, key_mask, cfg, training)
+    ctx = self_attention(P, pre, x, key_mask, cfg, training, _m(masks, ("attn", l)))
     a = ctx @ P[pre + "attention.output.dense.weight"].t() + P[pre + "attention.output.dense.bias"]
-    a = _dropout(a, cfg.hidden_dropout_prob, training)
+    a = _dropout(a, cfg.hidden_dropout_prob, training, _m(masks, ("h1", l)))
     x1 = F.layer_norm(
         a + x, (H,), P[pre + "attention.output.LayerNorm.weight"], P[pre + "attention.output.LayerNorm.bias"],
         cfg.layer_norm_eps,
@@ -206,7 +217,7 @@ def encoder_layer(P, l, x, key_mask, cfg: BertShape, training=False):
     u = x1 @ P[pre + "intermediate.dense.weight"].t() + P[pre + "intermediate.dense.bias"]
     h = gelu_erf(u)
     o = h @ P[pre + "output.dense.weight"].t() + P[pre + "output.dense.bias"]
-    o = _dropout(o, cfg.hidden_dropout_prob, training)
+    o = _dropout(o, cfg.hidden_dropout_prob, training, _m(masks, ("h2", l)))
     return F.layer_norm(
         o + x1, (H,), P[pre + "output.LayerNorm.weight"], P[pre + "output.LayerNorm.bias"], cfg.layer_norm_eps
     )
@@ -227,11 +238,14 @@ def pool(last_hidden, mask, pooling="average", normalize=False):
 
 
 def encoder_forward(P, ids, mask, cfg: BertShape, pooling="average", normalize=False, training=False,
-                    return_hidden=False):
-    x = embeddings(P, ids, cfg, training)
+                    return_hidden=False, masks=None):
+    """masks: the dropout outcome of a training-mode pass as multiplicative scales keep / (1 - p), keys "emb" [B,S,H],
+    ("attn", l) [B,heads,S,S], ("h1", l), ("h2", l) [B,S,H] (tests/dropout_ref.encoder_scales builds them from the
+    kernels' counter RNG); a site without an entry falls back to `training` (torch's own draws)."""
+    x = embeddings(P, ids, cfg, training, masks)
     hidden = [x]
     for l in range(cfg.num_hidden_layers):
-        x = encoder_layer(P, l, x, mask, cfg, training)
+        x = encoder_layer(P, l, x, mask, cfg, training, masks)
         hidden.append(x)
     emb = pool(x, mask, pooling, normalize)
     return (emb, hidden) if return_hidden else emb
@@ -316,7 +330,7 @@ def adamw_step(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay):
 
 
 # --------------------------------------------------------------------------------------
-# one full micro-step (src/moco.py:296-353 + train.py:263-264,324), dropout off
+# one full micro-step (src/moco.py:296-353 + train.py:263-264,324); dropout off, or on with given outcomes
 # --------------------------------------------------------------------------------------
 class MoCoState:
     def __init__(self, cfg: BertShape, Pq, queue, momentum, temperature, label_smoothing=0.0,
@@ -334,14 +348,17 @@ class MoCoState:
         self.v = {n: torch.zeros_like(t) for n, t in Pq.items()}
         self.opt_step = 0
 
-    def forward_backward(self, q_tokens, q_mask, k_tokens, k_mask, training=False, distill=None):
+    def forward_backward(self, q_tokens, q_mask, k_tokens, k_mask, training=False, distill=None, q_masks=None,
+                         k_masks=None):
         """distill = (teacher_embeddings, weight, multiplier): the student step of distill.py:263-278 — the gradient is
-        that of (1 - weight) * contrastive + weight * multiplier * distill_sim_loss(q, teacher)."""
+        that of (1 - weight) * contrastive + weight * multiplier * distill_sim_loss(q, teacher).
+        q_masks / k_masks: given dropout outcomes of the two encoders (encoder_forward's `masks`): the reference keeps
+        BOTH in train mode (train.py:246; src/moco.py:316-317 is a no-op guard after model.train())."""
         cfg = self.cfg
-        q = encoder_forward(self.Pq, q_tokens, q_mask, cfg, self.pooling, self.norm_query, training)
+        q = encoder_forward(self.Pq, q_tokens, q_mask, cfg, self.pooling, self.norm_query, training, masks=q_masks)
         with torch.no_grad():
             self.Pk = ema_update(self.Pk, {n: t.detach() for n, t in self.Pq.items()}, self.momentum)
-            k = encoder_forward(self.Pk, k_tokens, k_mask, cfg, self.pooling, self.norm_doc, training)
+            k = encoder_forward(self.Pk, k_tokens, k_mask, cfg, self.pooling, self.norm_doc, training, masks=k_masks)
         loss, logits = infonce_loss(q, k, self.queue.clone(), self.temperature, self.label_smoothing)
         if self.l2_from_init:
             for n, p in self.Pq.items():

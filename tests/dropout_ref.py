@@ -30,3 +30,68 @@ def keep_mask(seed: int, site: int, p: float, n: int) -> np.ndarray:
     w = np.where(e & np.uint32(2), hi, lo)
     d = np.where(e & np.uint32(1), w >> np.uint32(16), w & np.uint32(0xFFFF))
     return (d >= thr).astype(np.uint8)
+
+
+# ------------------------------------------------------------------------------------------------
+# the assembled encoder's dropout sites (czech_contriever_amd/csrc/encoder.hip: SITE_EMB, SITE_ATTN(l), SITE_H1(l),
+# SITE_H2(l); split-range shift +4) and the engine's per-forward seed (czech_contriever_amd/engine.py:_forward_impl)
+# ------------------------------------------------------------------------------------------------
+SITE_EMB = 1
+
+
+def site_attn(l):
+    return 16 * (l + 1) + 0
+
+
+def site_h1(l):
+    return 16 * (l + 1) + 1
+
+
+def site_h2(l):
+    return 16 * (l + 1) + 2
+
+
+SPLIT_SHIFT = 4
+
+
+def engine_seed(initial_seed: int, drop_calls: int, salt: int) -> int:
+    """Seed of an encoder's `drop_calls`-th TRAINING forward (counted from 1) in a process whose torch.initial_seed() is
+    `initial_seed`; salt = the encoder's role (MoCo: query 0, key 1)."""
+    return (initial_seed * 2654435761 + drop_calls * 40503 + (salt + 1) * 0x9E3779B1) & 0xFFFFFFFF
+
+
+def _scale(keep, p):
+    import torch
+    return torch.from_numpy(keep.astype(np.float32)) * float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
+
+
+def rows_scale(seed, site, p, rows, H):
+    """[rows, H] keep / (1 - p) of a row kernel launched on `rows` rows: element (r, c) is draw r * H + c."""
+    return _scale(keep_mask(seed, site, p, rows * H).reshape(rows, H), p)
+
+
+def attn_scale(seed, site, p, B, nh, S):
+    """[B, nh, S, S] keep / (1 - p) of an attention launch on B sequences: the draw index pitch is S rounded up to 4."""
+    S4 = (S + 3) // 4 * 4
+    return _scale(keep_mask(seed, site, p, B * nh * S * S4).reshape(B, nh, S, S4)[..., :S], p)
+
+
+def encoder_scales(seed, cfg, B, S, split=0):
+    """Every dropout site of one training forward of the encoder as multiplicative scales (keep / (1 - p)), keyed as
+    oracle.encoder_forward(masks=...) wants them: "emb", ("attn", l), ("h1", l), ("h2", l).  split > 0: the last layer ran
+    in the batch ranges [0, split) and [split, B) (czc_encoder_forward's split_batch): each range draws from index 0 of its
+    own launch, the second with its sites shifted by SPLIT_SHIFT."""
+    import torch
+    H, nh, L = cfg.hidden_size, cfg.num_attention_heads, cfg.num_hidden_layers
+    ph, pa = cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob
+    out = {}
+    if ph > 0:
+        out["emb"] = rows_scale(seed, SITE_EMB, ph, B * S, H).view(B, S, H)
+    for l in range(L):
+        ranges = [(0, B, 0)] if not (split and l == L - 1) else [(0, split, 0), (split, B - split, SPLIT_SHIFT)]
+        if pa > 0:
+            out[("attn", l)] = torch.cat([attn_scale(seed, site_attn(l) + sh, pa, nb, nh, S) for _, nb, sh in ranges])
+        if ph > 0:
+            out[("h1", l)] = torch.cat([rows_scale(seed, site_h1(l) + sh, ph, nb * S, H).view(nb, S, H) for _, nb, sh in ranges])
+            out[("h2", l)] = torch.cat([rows_scale(seed, site_h2(l) + sh, ph, nb * S, H).view(nb, S, H) for _, nb, sh in ranges])
+    return out

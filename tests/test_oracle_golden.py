@@ -206,3 +206,96 @@ def test_distill_loss_matches_reference(golden_dir, tag):
     assert abs(float(aux) - float(g[f"{tag}_loss"])) <= 1e-5 * abs(float(g[f"{tag}_loss"]))
     ref = t(g[f"{tag}_dstudent"])
     assert float((student.grad - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------
+# g15: TRAINING mode (dropout on) under given dropout outcomes -- the reference's modules in train() with
+# torch.nn.functional.dropout replaced by multiplication with masks from the kernels' counter RNG
+# ------------------------------------------------------------------------------------------------
+def test_training_mode_tiny_encoder_matches_reference_under_given_masks(golden_dir):
+    from tests import dropout_ref as D
+    g = load(golden_dir, "g15_train_masks.npz")
+    cfg = O.BertShape(**TINY)
+    ids, mask, cot = t(g["tiny_ids"]), t(g["tiny_mask"]), t(g["tiny_cot"])
+    masks = D.encoder_scales(int(g["tiny_dseed"]), cfg, *ids.shape)
+    # the masks really drop: about 10 % zeros at every site
+    for key, sc in masks.items():
+        z = float((sc == 0).float().mean())
+        assert 0.07 < z < 0.13, (key, z)
+    for pooling, norm in (("average", False), ("average", True), ("cls", False)):
+        P = {n: v.requires_grad_(True) for n, v in O.make_params(cfg, int(g["tiny_seed"])).items()}
+        emb = O.encoder_forward(P, ids, mask, cfg, pooling, norm, training=True, masks=masks)
+        tag = f"{pooling}_{int(norm)}"
+        assert torch.allclose(emb, t(g[f"tiny_emb_{tag}"]), atol=ATOL, rtol=1e-4), tag
+        (emb * cot).sum().backward()
+        for n, p in P.items():
+            ref = t(g[f"tiny_grad_{tag}::{n}"])
+            scale = max(1e-6, float(ref.abs().max()))
+            assert float((p.grad - ref).abs().max()) <= 2e-4 * scale + 1e-6, (tag, n)
+    # and it is NOT the eval-mode result (the fixture pins the dropped arithmetic, not a no-op)
+    with torch.no_grad():
+        ev = O.encoder_forward(O.make_params(cfg, int(g["tiny_seed"])), ids, mask, cfg, "average", False)
+    assert float((ev - t(g["tiny_emb_average_0"])).abs().max()) > 1e-2
+
+
+def test_training_mode_base_width_matches_reference_under_given_masks(golden_dir):
+    from tests import dropout_ref as D
+    g = load(golden_dir, "g15_train_masks.npz")
+    cfg = O.BertShape(**BASE1)
+    ids, mask, cot = t(g["base_ids"]), t(g["base_mask"]), t(g["base_cot"])
+    masks = D.encoder_scales(int(g["base_dseed"]), cfg, *ids.shape)
+    for pooling, norm in (("average", False), ("average", True)):
+        P = {n: v.requires_grad_(True) for n, v in O.make_params(cfg, int(g["base_seed"])).items()}
+        emb = O.encoder_forward(P, ids, mask, cfg, pooling, norm, training=True, masks=masks)
+        tag = f"{pooling}_{int(norm)}"
+        assert torch.allclose(emb, t(g[f"base_emb_{tag}"]), atol=ATOL, rtol=1e-4), tag
+        (emb * cot).sum().backward()
+        for n, p in P.items():
+            stat = g[f"base_gstat_{tag}::{n}"]
+            ref = t(g[f"base_grad_{tag}::{n}"])
+            got = p.grad.reshape(-1)[::int(stat[2])]
+            scale = max(1e-6, float(ref.abs().max()))
+            assert float((got - ref).abs().max()) <= 5e-4 * scale + 1e-6, (tag, n)
+            assert abs(float(p.grad.double().norm()) - stat[1]) <= 1e-4 * stat[1] + 1e-7, (tag, n)
+
+
+@pytest.mark.parametrize("tag,shape_kw", [("split3", TINY), ("split2b", BASE1)])
+def test_training_mode_split_last_layer_matches_reference_under_given_masks(golden_dir, tag, shape_kw):
+    from tests import dropout_ref as D
+    g = load(golden_dir, "g15_train_masks.npz")
+    cfg = O.BertShape(**shape_kw)
+    ids, mask = t(g[f"{tag}_ids"]), t(g[f"{tag}_mask"])
+    P = O.make_params(cfg, int(g[f"{tag}_seed"]))
+    masks = D.encoder_scales(int(g[f"{tag}_dseed"]), cfg, *ids.shape, split=int(g[f"{tag}_split"]))
+    with torch.no_grad():
+        emb = O.encoder_forward(P, ids, mask, cfg, "average", False, training=True, masks=masks)
+        whole = O.encoder_forward(P, ids, mask, cfg, "average", False, training=True,
+                                  masks=D.encoder_scales(int(g[f"{tag}_dseed"]), cfg, *ids.shape))
+    assert torch.allclose(emb, t(g[f"{tag}_emb"]), atol=ATOL, rtol=1e-4)
+    sp = int(g[f"{tag}_split"])
+    assert float((whole[sp:] - emb[sp:]).abs().max()) > 1e-3      # the second range's draws differ from an unsplit pass ...
+    assert torch.allclose(whole[:sp], emb[:sp], atol=1e-6)         # ... the first range's do not
+
+
+def test_training_mode_moco_steps_match_reference_under_given_masks(golden_dir):
+    from oracle.make_golden import ragged_batch
+    from tests import dropout_ref as D
+    g = load(golden_dir, "g15_train_masks.npz")
+    cfg = O.BertShape(**TINY)
+    P = O.make_params(cfg, 71)
+    queue = torch.nn.functional.normalize(O.det_uniform((cfg.hidden_size, 64), 72), dim=0)
+    st = O.MoCoState(cfg, P, queue, momentum=0.99, temperature=0.05, label_smoothing=0.1, norm_query=True, norm_doc=True)
+    B, S, init_seed = 8, 24, int(g["moco_init_seed"])
+    for step in range(3):
+        q_tokens, q_mask = ragged_batch(B, S, 7300 + step, cfg.vocab_size, [S, 17, 3, 24, 9, 24, 12, 20])
+        k_tokens, k_mask = ragged_batch(B, S, 7400 + step, cfg.vocab_size, [20, S, 5, 11, 24, 7, 24, 16])
+        qm = D.encoder_scales(D.engine_seed(init_seed, step + 1, 0), cfg, B, S)
+        km = D.encoder_scales(D.engine_seed(init_seed, step + 1, 1), cfg, B, S)
+        loss, q, k, stats = st.forward_backward(q_tokens, q_mask, k_tokens, k_mask, training=True, q_masks=qm, k_masks=km)
+        st.optimizer_step(1e-3 * O.warmup_linear(step, 2, 10, 0.0))
+        assert abs(float(loss) - float(g["moco_losses"][step])) < 2e-4, (step, float(loss), float(g["moco_losses"][step]))
+        assert torch.allclose(q, t(g["moco_q"][step]), atol=1e-4)
+        assert torch.allclose(k, t(g["moco_k"][step]), atol=1e-4)
+    assert torch.allclose(st.queue, t(g["moco_queue_final"]), atol=1e-4)
+    assert torch.allclose(st.Pq["encoder.layer.1.output.dense.weight"].detach()[::7, ::5], t(g["moco_wq_probe"]), atol=1e-5)
+    assert torch.allclose(st.Pk["encoder.layer.1.output.dense.weight"][::7, ::5], t(g["moco_wk_probe"]), atol=1e-6)
