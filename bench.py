@@ -97,16 +97,17 @@ def host_cpu_share():
     return min(n, 16) if quota is None else n
 
 
-def cpu_baseline(seq, cpu_batch=8, steps=2):
-    """The CPU oracle (fp32, the reference's arithmetic) timed on this host: identical micro-step,
-    B reduced to 8 (pairs/s is batch-insensitive on CPU).  kind = "port"."""
+def cpu_baseline(seq, cpu_batch=8, steps=3, queue_size=131072):
+    """The CPU oracle (fp32, the reference's arithmetic) timed on this host: identical micro-step against the full
+    131 072-slot queue, B reduced to 8 (pairs/s is batch-insensitive on CPU), 1 warm-up + `steps` >= 3 measured steps,
+    median.  kind = "port"."""
     from oracle import moco_bert_oracle as O
     cores = host_cpu_share()
     torch.set_num_threads(cores)
     log(f"cpu baseline: {cores} threads (affinity {len(os.sched_getaffinity(0))}, os.cpu_count {os.cpu_count()})")
     cfg = O.BertShape()
     P = O.make_params(cfg, 0)
-    queue = O.init_queue(768, 8192, 0)   # K=8192 slots: the head is 0.2 % of the step either way
+    queue = O.init_queue(768, queue_size, 0)
     st = O.MoCoState(cfg, P, queue, momentum=0.9995, temperature=0.05)
     g = torch.Generator().manual_seed(99)
     times = []
@@ -120,10 +121,11 @@ def cpu_baseline(seq, cpu_batch=8, steps=2):
         st.optimizer_step(1e-5)
         times.append(time.perf_counter() - t0)
         log(f"cpu baseline step {i}: {times[-1]:.2f} s")
-    med = sorted(times[1:])[len(times[1:]) // 2]
+    import statistics
+    med = statistics.median(times[1:])
     return {"value": round(cpu_batch / med, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} full fp32 micro-steps (1 warm-up) of the CPU oracle at B={cpu_batch}, S={seq}, "
-                      f"bert-base, queue 8192, dropout on; median {med:.2f} s/step; {cores} threads = the CPU share this job "
+            "sample": f"{steps} full fp32 micro-steps (after 1 warm-up) of the CPU oracle at B={cpu_batch}, S={seq}, "
+                      f"bert-base, queue {queue_size}, dropout on; median {med:.2f} s/step; {cores} threads = the CPU share this job "
                       f"is allowed (cgroup quota; the host shows {os.cpu_count()} logical CPUs, which a one-GPU job may not occupy)"}
 
 
@@ -253,6 +255,51 @@ def launch_ranks(n):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
+def newest_profile(suffix):
+    """profiles/r<N>_<suffix> with the largest round NUMBER (r10 after r9, not before r2)"""
+    import glob
+    import re
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", f"r*_{suffix}")):
+        m = re.match(r"r(\d+)_", os.path.basename(path))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), path)
+    return best[1] if best else None
+
+
+def gemm_source_sha1():
+    import hashlib
+    with open(os.path.join(ROOT, "czech_contriever_amd", "csrc", "gemm_bf16.hip"), "rb") as f:
+        return hashlib.sha1(f.read()).hexdigest()
+
+
+def attach_traffic(kernels):
+    """fetch_mb / write_mb per launch (rocprofv3 --pmc FETCH_SIZE x 2 and WRITE_SIZE, separate passes: tools/final_session.sh
+    -> tools/make_profiles.py -> profiles/r<N>_traffic_kernels.csv) next to each operation's algorithmic bytes.  Only while
+    gemm_bf16.hip still hashes to the source the counters were collected on (the file's last line names it)."""
+    path = newest_profile("traffic_kernels.csv")
+    if not path or not kernels:
+        return
+    import csv
+    with open(path) as f:
+        lines = f.read().splitlines()
+    meta = next((l for l in lines if l.startswith("#")), "")
+    if f"gemm_bf16.hip sha1 {gemm_source_sha1()}" not in meta:
+        return
+    rows = list(csv.DictReader([l for l in lines if not l.startswith("#")]))
+    by_op = {}
+    for r in rows:
+        for op in filter(None, (r.get("bench_ops") or "").split("|")):
+            by_op[op] = r
+    for k in kernels:
+        r = by_op.get(k["name"])
+        if r is not None:
+            k["fetch_mb"], k["write_mb"] = float(r["fetch_MB_per_launch"]), float(r["write_MB_per_launch"])
+            shared = [o for o in r["bench_ops"].split("|") if o and o != k["name"]]
+            if shared:
+                k["traffic_is_kernel_average_with"] = shared
+
+
 def kernel_table(rows, steps):
     """czc_prof rows -> per-operation dicts (ms per step, achieved TFLOP/s or GB/s, fraction of the bound's peak),
     largest first.  MFMA work is priced against the dense bf16 peak, byte-moving work against 8 TB/s HBM."""
@@ -261,7 +308,8 @@ def kernel_table(rows, steps):
         if calls == 0 or ms <= 0:
             continue
         per = ms / calls
-        d = {"name": name, "calls_per_step": round(calls / steps, 2), "ms_per_step": round(ms / steps, 4), "us_per_call": round(per * 1e3, 2)}
+        d = {"name": name, "calls_per_step": round(calls / steps, 2), "ms_per_step": round(ms / steps, 4), "us_per_call": round(per * 1e3, 2),
+             "algorithmic_mb": round(nbytes / 1e6, 2)}
         if flops > 0:
             tf = flops / (per * 1e-3) / 1e12
             d.update(bound="mfma", tflops=round(tf, 1), frac=round(tf / PEAK_BF16_TFLOPS, 4), gflop_per_call=round(flops / 1e9, 2))
@@ -271,6 +319,67 @@ def kernel_table(rows, steps):
         out.append(d)
     out.sort(key=lambda d: -d["ms_per_step"])
     return out
+
+
+class GpuTelemetry:
+    """Shader clock and package power of the device this rank runs on, read from the amdgpu sysfs files (what rocm-smi
+    reads; nothing is written, no setting is changed).  A background thread samples every `period` seconds."""
+
+    def __init__(self, device_index, period=0.25):
+        import glob
+        import threading
+        self.dir, self.samples, self.period = None, [], period
+        self._stop = threading.Event()
+        self._thread = None
+        try:
+            p = torch.cuda.get_device_properties(device_index)
+            want = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}."
+            for d in glob.glob("/sys/class/drm/card*/device"):
+                if os.path.basename(os.path.realpath(d)).startswith(want):
+                    self.dir = d
+        except Exception:
+            pass
+
+    def read(self):
+        """(sclk_mhz, package_w) right now; None for what cannot be read"""
+        import glob
+        mhz = watts = None
+        if self.dir:
+            try:
+                with open(os.path.join(self.dir, "pp_dpm_sclk")) as f:
+                    cur = [l for l in f.read().splitlines() if l.rstrip().endswith("*")]
+                mhz = float(cur[0].split(":")[1].lower().replace("mhz", "").replace("*", "").strip()) if cur else None
+            except Exception:
+                pass
+            for name in ("power1_input", "power1_average"):
+                try:
+                    with open(glob.glob(os.path.join(self.dir, "hwmon", "hwmon*", name))[0]) as f:
+                        watts = float(f.read()) / 1e6
+                    break
+                except Exception:
+                    continue
+        return mhz, watts
+
+    def start(self):
+        import threading
+        self.samples = []
+        self._stop.clear()
+
+        def loop():
+            while not self._stop.wait(self.period):
+                self.samples.append(self.read())
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        """median (sclk_mhz, package_w) over the second half of the samples taken since start()"""
+        import statistics
+        self._stop.set()
+        if self._thread:
+            self._thread.join()
+        half = self.samples[len(self.samples) // 2:]
+        med = lambda v: round(statistics.median(v), 1) if v else None
+        return med([a for a, _ in half if a is not None]), med([b for _, b in half if b is not None])
 
 
 def log(msg):
@@ -288,6 +397,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", type=int, default=3,
                     help="steps run AFTER the timed region with per-operation hipEvents, for roofline.kernels (0 = skip)")
+    ap.add_argument("--steady-steps", type=int, default=200,
+                    help="when --steps < 50: steps run AFTER the timed region (never part of `value`) for the line's `steady_state` "
+                         "object -- the chip reaches its package power cap about a second into the load, so a short timed region "
+                         "straddles the clock ramp (0 = skip)")
     ap.add_argument("--no-dropout", action="store_true", help="diagnostic only: the headline keeps dropout on")
     ap.add_argument("--ragged", action="store_true",
                     help="informational: sample lengths as the reference's random crops give them (27..130 of 256), pad id 0")
@@ -400,6 +513,39 @@ def main():
     L.check(lib.czc_probe_read(ctypes.byref(tot_ms), ctypes.byref(cnt)))
     L.check(lib.czc_probe_arm(0, 0, 0, 0, 0, 0, 0))
 
+    # steady state (outside the timed region, every rank: the steps hold collectives): BASELINE.md §3 asks for >= 50 measured
+    # steps; the driver's 5 + 20 straddle the power ramp.  Clock and package power are sampled from sysfs beside it.
+    # The same steps time the main stream's waits for the two exchanges (0 on one rank; on N ranks: what the collectives cost
+    # beyond the compute that covers them).
+    steady = None
+    n_tail = args.steady_steps if args.steps < 50 else 0
+    if n_tail > 0:
+        tele = GpuTelemetry(local_rank)
+        kxs = list(getattr(model.module, "_key_exchange", {}).values())
+        model.exposed = []
+        for kx in kxs:
+            kx.exposed = []
+        skip = min(20, n_tail // 4)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tele.start()
+        for i in range(n_tail):
+            if i == skip:
+                ev0.record()
+            step(args.warmup + args.steps + i)
+        ev1.record()
+        torch.cuda.synchronize()
+        sclk, watts = tele.stop()
+        n_meas = n_tail - skip
+        steady = {"ms_per_step": round(ev0.elapsed_time(ev1) / n_meas, 3), "steps": n_meas,
+                  "pairs_per_s": round(args.batch * world * n_meas / (ev0.elapsed_time(ev1) * 1e-3), 1),
+                  "sclk_mhz": sclk, "package_w": watts,
+                  "allreduce_exposed_ms": round(model.exposed_ms() / n_tail, 4),
+                  "key_exchange_exposed_ms": round(sum(kx.exposed_ms() for kx in kxs) / n_tail, 4),
+                  "note": "rank 0's device and stream; steps run after the timed region, not part of `value`"}
+        model.exposed = None
+        for kx in kxs:
+            kx.exposed = None
+
     # per-operation table: a few more steps, OUTSIDE the timed region, with a hipEvent pair around every operation
     kernels = None
     # (the per-operation event pairs mean something only while operations run one after another: the key encoder's
@@ -413,6 +559,7 @@ def main():
             step(args.warmup + args.steps + i)
         torch.cuda.synchronize()
         kernels = kernel_table(L.prof_report(), args.kernel_table)
+        attach_traffic(kernels)
         if os.environ.get("CZC_BENCH_ALLOPS"):       # dev: every operation of a step, largest first
             for k in kernels:
                 log(f"op {k['name']:44s} x{k['calls_per_step']:6.1f} {k['us_per_call']:9.2f} us  {k['ms_per_step']:8.3f} ms/step  "
@@ -434,15 +581,11 @@ def main():
         # the commit of gemm_bf16.hip it was collected on, and a figure collected on another version of the kernel is
         # reported as null rather than passed off as current
         traffic, traffic_note = None, None
-        import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_ffn_up.json")))   # the newest round's collection
-        tpath = cands[-1] if cands else ""
+        tpath = newest_profile("pmc_ffn_up.json") or ""
         if os.path.exists(tpath):
             with open(tpath) as f:
                 pmc = json.load(f)
-            import hashlib
-            with open(os.path.join(ROOT, "czech_contriever_amd", "csrc", "gemm_bf16.hip"), "rb") as f:
-                now = hashlib.sha1(f.read()).hexdigest()
+            now = gemm_source_sha1()
             if pmc.get("gemm_bf16_sha1") == now:
                 traffic = pmc.get("hbm_bytes_per_launch")
             traffic_note = (f"rocprofv3 --pmc passes of commit {pmc.get('commit')}, gemm_bf16.hip sha1 {pmc.get('gemm_bf16_sha1')}"
@@ -460,7 +603,7 @@ def main():
                                    "queue_size=131072, temperature=0.05" if headline else
                                    f"NON-HEADLINE diagnostic: objective={args.objective} batch={args.batch} seq={args.seq} ragged={args.ragged} queue={args.queue} dropout={not args.no_dropout}",
                        "global_batch": args.batch * world, "seq_len": args.seq, "queue_size": args.queue,
-                       "parallelism": f"dp{world}", "weights": "random-init bert-base (seed 0)", "dropout": 0.0 if args.no_dropout else 0.1,
+                       "parallelism": f"dp{world}", "dp": model.settings(), "weights": "random-init bert-base (seed 0)", "dropout": 0.0 if args.no_dropout else 0.1,
                        "step": "q fwd+bwd, EMA, k fwd, InfoNCE fwd+bwd, all-gather+enqueue, grad all-reduce, AdamW"
                                if args.objective == "moco" else
                                "MoCo step + synthetic teacher embeddings (3584-d) + similarity-matrix MSE fwd+bwd"
@@ -475,12 +618,13 @@ def main():
                          "kernel_ms": round(kern_ms, 4), "launches_timed": cnt.value, "traffic_source": traffic_note,
                          "kernel_choice": "the largest single GEMM shape below its siblings' rate (FFN-up with its two-output "
                                           "GELU epilogue); by time the largest operations are the ones listed first in `kernels`",
-                         "kernels": None if kernels is None else kernels[:8],
+                         "kernels": None if kernels is None else kernels[:16],
                          "hbm_kernels": None if kernels is None else [k for k in kernels if k["bound"] == "hbm"][:10],
                          "whole_step_frac": None if args.ragged else round(value * flop_per_pair / (world * PEAK_BF16_TFLOPS * 1e12), 4)},
             "step_ms": (lambda v: {"p10": round(v[len(v) // 10], 3), "median": round(v[len(v) // 2], 3), "p90": round(v[(9 * len(v)) // 10], 3)})(
                 sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))),
             "final_loss": round(float(last.detach()), 4),
+            "steady_state": steady,
         }
         if world == 1 and not args.no_cpu_baseline and args.objective == "moco":
             out["cpu_baseline"] = cpu_baseline(args.seq)

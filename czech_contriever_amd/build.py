@@ -1,6 +1,7 @@
 """Builds libczc.so (the gfx950 kernels + C ABI) in-tree with hipcc.  No GPU needed: hipcc cross-compiles."""
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -19,6 +20,23 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-res
 # eight values of a segment; scalar v_fmaak_f32 with literal constants, stage by stage, is 25 % fewer VALU cycles
 # attention.hip: the same packing of the softmax / dS arithmetic beside the MFMAs (backward 326 -> 322 us)
 EXTRA_FLAGS = {"gemm_bf16.hip": ["-fno-slp-vectorize"], "attention.hip": ["-fno-slp-vectorize"]}
+
+
+def source_hash(extra=()) -> str:
+    """sha1 over every source and header of the library plus the compiler flags: compiled into the library
+    (czc_source_hash) so that lib.load() can tell a binary built from OTHER sources than the ones beside it."""
+    h = hashlib.sha1()
+    for rel in SOURCES + HEADERS:
+        path = os.path.normpath(os.path.join(CSRC, rel))
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update(repr((FLAGS, sorted(EXTRA_FLAGS.items()), list(extra))).encode())
+    return h.hexdigest()
+
+
+def _hash_flag(digest: str):
+    return [f'-DCZC_SOURCE_HASH="{digest}"']
 
 
 def _hipcc() -> str:
@@ -42,11 +60,13 @@ def build_variant(suffix: str, defines, verbose: bool = True) -> str:
     obj = OBJ + "_" + suffix
     os.makedirs(obj, exist_ok=True)
     out = os.path.join(HERE, f"libczc_{suffix}.so")
+    digest = source_hash(defines)
 
     def one(src):
         sp = os.path.join(CSRC, src)
         op = os.path.join(obj, os.path.splitext(src)[0] + ".o")
-        cmd = [_hipcc()] + FLAGS + list(defines) + EXTRA_FLAGS.get(src, []) + (["-x", "hip"] if sp.endswith(".cpp") else []) + ["-c", sp, "-o", op]
+        cmd = [_hipcc()] + FLAGS + list(defines) + EXTRA_FLAGS.get(src, []) + (_hash_flag(digest) if src == "api.cpp" else []) \
+            + (["-x", "hip"] if sp.endswith(".cpp") else []) + ["-c", sp, "-o", op]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {sp}:\n{r.stdout}\n{r.stderr}")
@@ -64,16 +84,22 @@ def build_variant(suffix: str, defines, verbose: bool = True) -> str:
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    digest = source_hash()
+    stamp = os.path.join(OBJ, "source_hash.txt")
+    old = open(stamp).read().strip() if os.path.exists(stamp) else ""
     jobs = []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         op = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
-        if force or _stale(op, [sp] + hdrs):
+        # api.cpp carries the hash of ALL sources: it is recompiled whenever any of them (or a flag) changed
+        if force or _stale(op, [sp] + hdrs) or (src == "api.cpp" and old != digest):
             jobs.append((sp, op))
 
     def compile_one(job):
         sp, op = job
-        cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(os.path.basename(sp), []) + (["-x", "hip"] if sp.endswith(".cpp") else []) + ["-c", sp, "-o", op]
+        base = os.path.basename(sp)
+        cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(base, []) + (_hash_flag(digest) if base == "api.cpp" else []) \
+            + (["-x", "hip"] if sp.endswith(".cpp") else []) + ["-c", sp, "-o", op]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {sp}:\n{r.stdout}\n{r.stderr}")
@@ -92,6 +118,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
         if verbose:
             print(f"[czc build] linked {LIB}", file=sys.stderr)
+    with open(stamp, "w") as f:
+        f.write(digest)
     return LIB
 
 

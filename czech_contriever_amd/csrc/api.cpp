@@ -98,6 +98,12 @@ extern "C" int64_t czc_prof_read(char* buf, int64_t len) {
 
 extern "C" const char* czc_last_error(void) { return czc::g_err; }
 extern "C" int czc_abi_version(void) { return CZC_ABI_VERSION; }
+#ifndef CZC_SOURCE_HASH
+#define CZC_SOURCE_HASH "unknown"
+#endif
+// (the marker lets the loader read the hash from the file's bytes, without mapping a binary it may be about to replace)
+static const char k_source_hash[] = "CZC_SOURCE_HASH=" CZC_SOURCE_HASH;
+extern "C" const char* czc_source_hash(void) { return k_source_hash + 16; }
 
 extern "C" int czc_event_create(czc_event_t* ev) {
   CZC_REQUIRE(ev, "czc_event_create: null argument");

@@ -24,6 +24,7 @@ struct GemmArgs {
   int fast_addr;         // both operands span < 2 GiB: DMA pieces may use 32-bit lane offsets from a scalar base
   int store_pol;         // cache policy of the bf16 output stores: 0 plain, 1 sc1, 2 nt
   int cfg;               // tile configuration: 0 = default, 1 = 256x256 (8 waves), 2 = 128x128 (4 waves, 2 WG/CU)
+  int xcd8;              // 1 = the device dispatches workgroups round-robin over 8 XCDs (256 CUs): split-K launches are laid out by XCD
   float alpha;           // head: 1/T
   float beta;            // head: eps/(K+1)
   // EPI_FILTER (flat index, coarse bf16 scan): row m = query, column n = passage row of this chunk.  An entry is appended to

@@ -25,7 +25,6 @@
 // The MFMA is issued as D = B_frag x A_frag, i.e. the accumulator tile is C^T: a lane owns one
 // output row m and four consecutive columns n, so bias loads are float4 and the bf16 tile is put
 // into LDS with 8-byte writes, then streamed out as whole 128-B row segments.
-#include <stdlib.h>
 
 #include "czc_common.h"
 #include "gemm_args.h"
@@ -241,8 +240,9 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
   constexpr int WNC = TN * 16;  // columns per wave
   constexpr int TILE_BYTES_A = CF::TILE_A, BUF_BYTES = CF::BUF;
 
-  // Split-K launches (f32 slabs, one workgroup per (tile, split)): workgroups are dispatched round-robin over the 8 XCDs in
-  // linear order, so with split = blockIdx.y the 36 tiles of one split -- which share that split's K-range of BOTH
+  // Split-K launches (f32 slabs, one workgroup per (tile, split); this covers EVERY split-K EPI_F32 caller -- the weight
+  // gradients and the head's dq alike -- whose tiles inside a split are then walked row-major instead of by swizzle_tile):
+  // workgroups are dispatched round-robin over the 8 XCDs in linear order, so with split = blockIdx.y the 36 tiles of one split -- which share that split's K-range of BOTH
   // operands -- were spread over all 8 L2s, and every L2 fetched nearly every panel (PMC: 1.43 GB from beyond L2 per
   // weight-gradient launch against 0.50 GB of operands).  Here each XCD takes a contiguous run of the split-major
   // (split, tile) list instead: an L2 sees one or two splits' panels, each tile row's A block and the B blocks once.
@@ -250,7 +250,9 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_kernel(const GemmArgs a) {
 #ifdef CZC_NO_XCD_SPLIT   // A/B builds: the mapping before round 3's last change
   const bool by_xcd = false;
 #else
-  const bool by_xcd = EPI == EPI_F32 && gridDim.y > 1;
+  // (a.xcd8: set by the host from the CU count.  The remap below is a bijection of (split, tile) for any grid, so results
+  //  do not depend on it; on a partitioned device or another part it would only scatter locality, so it stays off there)
+  const bool by_xcd = EPI == EPI_F32 && gridDim.y > 1 && a.xcd8;
 #endif
   if (by_xcd) {
     const int nt_ = a.tiles_m * a.tiles_n;
@@ -930,12 +932,13 @@ static int launch_cfg(GemmArgs a, int splits, hipStream_t st) {
   a.store_pol = g_store_pol >= 0 ? g_store_pol : (a.N >= 2048 ? 2 : 0);
   // bf16 epilogues run persistent (one workgroup per resident slot, see the kernel); the split-K and head-LSE
   // forms keep one workgroup per tile
-  static int slots = 0;
+  static int slots = 0, xcd8 = 0;
   if (!slots) {
     int dev = 0, cus = 0;
     CZC_HIP(hipGetDevice(&dev));
     CZC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     slots = cus * (160 * 1024 / CF::LDS);
+    xcd8 = cus == 256 ? 1 : 0;   // MI355X in SPX mode: 8 XCDs x 32 CUs (HIP has no XCD-count attribute; a CPX partition shows 32 CUs)
 #ifdef CZC_SLOTS_OVERRIDE
     slots = CZC_SLOTS_OVERRIDE;   // diagnostic builds: a persistent launch on part of the chip
 #endif
@@ -950,6 +953,7 @@ static int launch_cfg(GemmArgs a, int splits, hipStream_t st) {
   // wide outputs (FFN-up, its backward): six column tiles per sweep keep that group's B panels (6 x 256 x K) in L2 for
   // all the row tiles under them (PMC: FETCH 558 -> 433 MB per FFN-up launch, -2 % time); split-K products and
   // narrow outputs keep the plain row-major order
+  a.xcd8 = xcd8;
   a.group_n = (a.tiles_n >= 12 && splits == 1) ? 6 : a.tiles_n;
   const int ntiles = a.tiles_m * a.tiles_n;
   // (measured, interleaved A/B at 65536 x {768, 2304, 3072}: persistent -1..-3 % for the bias / store / add / dGELU

@@ -3,7 +3,6 @@
 // Each runs as ONE launch over all 108.9 M elements (the reference issues ~600 tiny launches for
 // the EMA alone, src/moco.py:260-269), 16 B per lane per access, grid-stride, and refreshes the
 // bf16 mirror of the matrix region in the same pass so no separate cast pass is needed.
-#include <stdlib.h>
 
 #include "czc_common.h"
 

@@ -82,6 +82,7 @@ SIGNATURES = {
     "czc_index_candidate_capacity": (i64, [i32]),
     "czc_index_begin": (i32, [vp, vp, i32, vp]),
     "czc_index_scan": (i32, [vp, i64, i32, i64, vp, i32, i32, i32, vp, vp, vp, vp, i64, vp]),
+    "czc_source_hash": (C.c_char_p, []),
     "czc_index_finish": (i32, [vp, vp, vp, i64, i32, i32, vp, vp, vp]),
     "czc_index_coarse_capacity": (i64, [i32]),
     "czc_index_coarse_epsilon": (f32, []),
@@ -110,14 +111,50 @@ def load():
     path = LIB_PATH if not variant else os.path.join(os.path.dirname(LIB_PATH), f"libczc_{variant}.so")
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing (CZC_LIB_VARIANT={variant})")
+    if not variant:
+        path = _fresh_or_rebuilt(path)
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError = a symbol czc.h declares is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.czc_abi_version() != 5:
+    if lib.czc_abi_version() != 6:
         raise RuntimeError("libczc.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def _embedded_hash(path):
+    """czc_source_hash() of the binary at `path`, read from the file's bytes (api.cpp keeps it behind a marker): a stale
+    library is never mapped, so the rebuilt file of the same name is the one that gets loaded."""
+    import mmap
+    marker = b"CZC_SOURCE_HASH="
+    with open(path, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as m:
+        i = m.find(marker)
+        if i < 0:
+            return "none"
+        j = m.find(b"\0", i)
+        return m[i + len(marker):j].decode("ascii", "replace")
+
+
+def _fresh_or_rebuilt(path):
+    """The binary must come from the sources beside it (the .so is git-ignored and travels prebuilt: a stale one would
+    otherwise run silently).  CZC_SKIP_HASH_CHECK=1 opts out (a deployment that ships the binary without csrc/)."""
+    if os.environ.get("CZC_SKIP_HASH_CHECK") == "1":
+        return path
+    from . import build as _b
+    if not all(os.path.exists(os.path.normpath(os.path.join(_b.CSRC, rel))) for rel in _b.SOURCES + _b.HEADERS):
+        return path                       # no sources to compare with
+    want = _b.source_hash()
+    have = _embedded_hash(path)
+    if have == want:
+        return path
+    try:
+        _b.build(verbose=False)
+    except Exception as e:
+        raise RuntimeError(f"{path} was built from other sources (hash {have}, sources {want}) and cannot be rebuilt: {e}")
+    if _embedded_hash(path) != want:
+        raise RuntimeError(f"{path} is stale (hash {have}, sources {want}) even after a rebuild")
+    return path
 
 
 def prof_report():

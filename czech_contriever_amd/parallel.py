@@ -22,6 +22,7 @@ Two exchanges per micro-step, both on side HIP streams:
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -84,6 +85,13 @@ class KeyExchange:
         self.split_event = self.keys_event = self.head_event = self.done_event = None
         self._bufs = {}
         self.gathered = None
+        self.exposed = None        # a list: (start, stop) timing events around the main stream's wait for the enqueue
+
+    def exposed_ms(self):
+        """Main-stream time spent waiting for the key exchange + enqueue since `exposed` was set to a list (after a device
+        synchronisation): what the exchange costs the step beyond what the InfoNCE head covers; 0 on one rank."""
+        ev, self.exposed = self.exposed or [], [] if self.exposed is not None else None
+        return sum(a.elapsed_time(b) for a, b in ev)
 
     def _events(self):
         if self.split_event is None:
@@ -163,11 +171,28 @@ class KeyExchange:
         with torch.cuda.stream(self.stream):
             fn(self.gathered)
             L.check(lib.czc_event_record(self.done_event, self.stream.cuda_stream))
+        pair = _timing_pair() if self.exposed is not None else None
+        if pair:
+            pair[0].record()
         L.check(lib.czc_stream_wait_event(L.stream_ptr(), self.done_event))
+        if pair:
+            pair[1].record()
+            self.exposed.append(pair)
+
+
+def _timing_pair():
+    return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
 
 class DataParallel(nn.Module):
-    """`.module` is the wrapped MoCo (same attribute the reference reads from its DDP wrapper)."""
+    """`.module` is the wrapped MoCo (same attribute the reference reads from its DDP wrapper).
+
+    Two settings no 8-GPU run has tuned yet are read ONCE here from the environment, so the first such run can sweep
+    them without a code change (bench.py echoes them in its line's `config`):
+      CZC_DP_CHUNK_LAYERS=<n>   layers per backward range = per gradient all-reduce (default 3: 85 MB slices, 5 collectives)
+      CZC_DP_PER_TILE=0|1|auto  GEMM launches beside a collective: 1 = one workgroup per output tile from the first range's
+                                all-reduce to the end of the backward (czc_gemm_set_tile(16)), 0 = keep the persistent
+                                launches, auto = 1 (the conservative choice until it has been measured)"""
 
     def __init__(self, module: nn.Module, optimizer=None, chunk_layers: int = 3, process_group=None):
         """process_group: the ranks that hold replicas (default: all; the students of a teacher/student run otherwise)."""
@@ -175,6 +200,16 @@ class DataParallel(nn.Module):
         self.module = module
         self._group = process_group
         self._world = world(process_group)
+        env_chunk = os.environ.get("CZC_DP_CHUNK_LAYERS")
+        if env_chunk:
+            chunk_layers = max(1, int(env_chunk))
+        mode = os.environ.get("CZC_DP_PER_TILE", "auto").lower()
+        if mode not in ("0", "1", "auto"):
+            raise ValueError(f"CZC_DP_PER_TILE={mode!r}: 0, 1 or auto")
+        self.chunk_layers = chunk_layers
+        self.per_tile_mode = mode
+        self._use_per_tile = mode != "0"
+        self.exposed = None        # a list: (start, stop) timing events around the main stream's waits for the all-reduces
         self._encoders = [m for m in module.modules() if isinstance(m, FlatBertEncoder)
                           and any(p.requires_grad for p in m._plist)]
         self._comm = None
@@ -218,7 +253,7 @@ class DataParallel(nn.Module):
                 self._done.record()
                 if hi <= enc._n_mat:
                     self._done_mat = self._done
-            if not self._per_tile:
+            if self._use_per_tile and not self._per_tile:
                 # The GEMMs' persistent launch sizes its grid to ALL the CUs; with RCCL's kernels holding some of them
                 # the last workgroups would start a whole pass late.  One workgroup per output tile degrades gracefully
                 # instead (include/czc.h, czc_gemm_set_tile) -- only for the launches that can run beside a collective:
@@ -233,15 +268,33 @@ class DataParallel(nn.Module):
             L.check(L.load().czc_gemm_set_tile(0))
             self._per_tile = False
 
+    def settings(self) -> dict:
+        return {"chunk_layers": self.chunk_layers, "per_tile": self.per_tile_mode, "world": self._world}
+
+    def exposed_ms(self):
+        """Main-stream time spent waiting for gradient all-reduces since `exposed` was set to a list (after a device
+        synchronisation): the part of the collectives the backward did not cover; 0 on one rank."""
+        ev, self.exposed = self.exposed or [], [] if self.exposed is not None else None
+        return sum(a.elapsed_time(b) for a, b in ev)
+
+    def _wait_event(self, event):
+        pair = _timing_pair() if self.exposed is not None else None
+        if pair:
+            pair[0].record()
+        torch.cuda.current_stream().wait_event(event)
+        if pair:
+            pair[1].record()
+            self.exposed.append(pair)
+
     def wait(self):
         """The main stream waits for every gradient all-reduce issued so far."""
         if self._done is not None:
-            torch.cuda.current_stream().wait_event(self._done)
+            self._wait_event(self._done)
             self._done = None
         self._done_mat = None
 
     def wait_matrices(self):
         """The main stream waits for the all-reduces of the weight-matrix ranges (not for the vectors + embeddings slice)."""
         if self._done_mat is not None:
-            torch.cuda.current_stream().wait_event(self._done_mat)
+            self._wait_event(self._done_mat)
             self._done_mat = None

@@ -310,6 +310,8 @@ def main(argv=None):
 
     model, optimizer, scheduler, step = build_student(opt, model_class)
     logger.info(utils.get_parameters(model))
+    if step > 0:   # resumed: continue the counter-based dropout streams instead of replaying the masks of steps 0..n (as train.py)
+        model.set_dropout_position(step * max(1, opt.target_batch_size // (opt.per_gpu_batch_size * max(1, world - 1))))
     if world > 1:
         from czech_contriever_amd.parallel import DataParallel
         model = DataParallel(model, optimizer, process_group=student_group)

@@ -30,13 +30,16 @@ extern "C" {
 #define CZC_ERR_INVALID 1
 #define CZC_ERR_HIP 2
 
-#define CZC_ABI_VERSION 5
+#define CZC_ABI_VERSION 6
 
 typedef void* czc_stream_t; /* hipStream_t */
 typedef void* czc_event_t;  /* hipEvent_t (timing disabled) */
 
 const char* czc_last_error(void);
 int czc_abi_version(void);
+/* sha1 (hex) over the library's sources, headers and compiler flags, fixed at build time (czech_contriever_amd/build.py:
+ * source_hash): the loader compares it with the sources beside the binary and refuses -- or rebuilds -- a stale one. */
+const char* czc_source_hash(void);
 
 /* Stream ordering without torch types: events the caller creates once and reuses (hipEventDisableTiming).
  * czc_event_record(ev, s): ev marks the work enqueued on s so far; czc_stream_wait_event(s, ev): work enqueued on s

@@ -95,3 +95,34 @@ def encoder_scales(seed, cfg, B, S, split=0):
             out[("h1", l)] = torch.cat([rows_scale(seed, site_h1(l) + sh, ph, nb * S, H).view(nb, S, H) for _, nb, sh in ranges])
             out[("h2", l)] = torch.cat([rows_scale(seed, site_h2(l) + sh, ph, nb * S, H).view(nb, S, H) for _, nb, sh in ranges])
     return out
+
+
+class DeviceScales:
+    """encoder_scales() for shapes whose masks are too many for numpy (B 256 x 12 heads x 256 x 256 per layer): the same
+    dict interface (`get`), each site drawn on demand by czc_dropout_mask -- the kernels' own czc_keep, equal to keep_mask
+    above element for element (tests/test_gpu_dropout_parity.py checks that) -- and copied to the host."""
+
+    def __init__(self, seed, cfg, B, S, device):
+        self.seed, self.cfg, self.B, self.S, self.device = seed, cfg, B, S, device
+
+    def get(self, key, default=None):
+        import torch
+        from czech_contriever_amd import ops
+        cfg, B, S = self.cfg, self.B, self.S
+        H, nh = cfg.hidden_size, cfg.num_attention_heads
+        if key == "emb":
+            site, p, shape = SITE_EMB, cfg.hidden_dropout_prob, (B, S, H)
+        else:
+            kind, l = key
+            site = {"attn": site_attn, "h1": site_h1, "h2": site_h2}[kind](l)
+            p = cfg.attention_probs_dropout_prob if kind == "attn" else cfg.hidden_dropout_prob
+            shape = (B, nh, S, (S + 3) // 4 * 4) if kind == "attn" else (B, S, H)
+        if p <= 0:
+            return default
+        n = 1
+        for d in shape:
+            n *= d
+        keep = ops.dropout_mask(self.seed, site, p, n, self.device).view(shape)
+        if key != "emb" and key[0] == "attn":
+            keep = keep[..., :S]
+        return keep.cpu().to(torch.float32) * float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))

@@ -175,3 +175,81 @@ def test_teacher_student_exchange_world3_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok"), (2, "ok")], res
+
+
+def _student_dp_worker(rank, world, port, out):
+    """distill.py's layout -- rank 0 the teacher, ranks 1..W-1 student replicas -- with the students' gradient exchange under
+    DataParallel(process_group=students) and update_freq = 2 (train.py / distill.py accumulate micro-steps and, like the
+    reference's DDP without no_sync (train.py:263-266, distill.py:466-470), all-reduce on EVERY micro-step).  The encoder
+    backward itself needs a GPU; here the hook protocol of FlatBertEncoder._backward_impl is driven by hand with known
+    per-rank gradients: pre-access wait, accumulate, ranges top-down, tail, post-backward."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      CZC_DP_CHUNK_LAYERS="2", CZC_DP_PER_TILE="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from czech_contriever_amd import parallel
+        students = dist.new_group(list(range(1, world)))      # every rank creates the group, as distill.py does
+        if rank == 0:
+            dist.barrier()                                    # the teacher takes no part in the students' collectives
+            out.put((rank, "ok"))
+            return
+        from src.contriever import Contriever, bert_config
+        enc = Contriever(bert_config(vocab_size=64, hidden_size=64, num_hidden_layers=4, num_attention_heads=1,
+                                     intermediate_size=128, max_position_embeddings=16))
+        dp = parallel.DataParallel(enc, process_group=students)
+        assert dp.settings() == {"chunk_layers": 2, "per_tile": "0", "world": world - 1}   # the env knobs, read once
+        assert enc.backward_chunk_layers == 2
+        n, nl = enc.flat_params.numel(), 4
+        la = enc._n_mat // nl
+        ranges = []
+        orig = dp._reduce_range
+        dp._reduce_range = lambda e, lo, hi: (ranges.append((lo, hi)), orig(e, lo, hi))[1]
+        enc._range_hooks = [dp._reduce_range]
+
+        def micro_backward(m, accumulate):
+            for hook in enc._pre_grad_access:                 # an earlier all-reduce may still own the array
+                hook()
+            g = O.det_uniform((n,), 500 + 10 * m + rank)
+            if accumulate:
+                enc._flat_grad += g
+            else:
+                enc._flat_grad = g.clone()
+            hi = nl
+            while hi > 0:                                     # FlatBertEncoder._backward_impl: ranges of chunk layers, top first
+                lo = max(0, hi - enc.backward_chunk_layers)
+                for hook in enc._range_hooks:
+                    hook(enc, lo * la, hi * la)
+                hi = lo
+            for hook in enc._range_hooks:
+                hook(enc, enc._n_mat, n)
+            for hook in enc._post_backward:
+                hook(enc)
+
+        micro_backward(0, False)
+        micro_backward(1, True)
+        dp.wait()
+        mean = lambda m: sum(O.det_uniform((n,), 500 + 10 * m + r) for r in range(1, world)) / (world - 1)
+        # averaging the accumulated array on every micro-step: mean_r(mean(g0) + g1_r) = mean(g0) + mean(g1)
+        assert torch.allclose(enc._flat_grad, mean(0) + mean(1), atol=1e-6)
+        assert ranges[:3] == [(2 * la, 4 * la), (0, 2 * la), (enc._n_mat, n)] and len(ranges) == 6
+        assert dp.exposed_ms() == 0.0                         # no device, nothing timed
+        dist.barrier()
+        out.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        out.put((rank, repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_student_group_data_parallel_world3_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_student_dp_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok"), (2, "ok")], res

@@ -111,6 +111,20 @@ def test_distill_cli_one_process(tmp_path, monkeypatch):
     ck = torch.load(os.path.join(out, "checkpoint", "step-3", "checkpoint.pth"), map_location="cpu", weights_only=False)
     assert ck["step"] == 3 and int(ck["model"]["queue_ptr"]) == (3 * 2 * 8) % 64   # update_freq 2
     assert torch.isfinite(ck["model"]["encoder_q.encoder.layer.0.output.dense.weight"]).all()
+    # auto-resume from `latest` (step 3 = 6 micro-steps at update_freq 2): the dropout streams continue there instead of
+    # replaying the masks of steps 0..2 (train.py does the same)
+    seen = {}
+    loop = distill.train_student
+
+    def spy(opt, model, *a, **kw):
+        m = model.module if hasattr(model, "module") else model
+        seen.update(q=m.encoder_q.dropout_state(), k=m.encoder_k.dropout_state())
+        return loop(opt, model, *a, **kw)
+    monkeypatch.setattr(distill, "train_student", spy)
+    distill.main(["--retriever_model_id", mdir, "--output_dir", out, "--save_dir", out, "--target_batch_size", "16",
+                  "--teacher", "synthetic:48"] + [a if a != "3" else "5" for a in CLI])
+    assert seen == {"q": {"salt": 0, "calls": 6}, "k": {"salt": 1, "calls": 6}}, seen
+    monkeypatch.setattr(distill, "train_student", loop)
     # a BERT teacher from a checkpoint of this repo (decode -> re-tokenise -> encode on libczc)
     tdir = _model_dir(tmp_path / "t", vocab=True)
     torch.save({"opt": types.SimpleNamespace(retriever_model_id=tdir, pooling="average"), "step": 0,

@@ -538,3 +538,25 @@ def test_key_encoder_on_second_stream_changes_nothing(gpu, tmp_path, dropout):
     for a, b in ((wqa, wqb), (wka, wkb)):
         d = (a - b).abs()
         assert float(d.max()) < 2.5e-3 and float(d.mean()) < 2e-5, (float(d.max()), float(d.mean()))
+
+
+def test_no_grad_pass_and_differentiable_pass_agree(gpu):
+    """One encoder, dropout 0, same batch: the no_grad pass (key encoder / inference: FFN-up keeps gelu(u) only, evaluated on
+    the fp32 sum -- CZC_EPI_BIAS_GELU_ONLY) against the differentiable pass (gelu and gelu' evaluated on the bf16-rounded
+    pre-activation, which the backward needs).  The two roundings differ inside bf16 noise; nothing of the reference pins
+    the asymmetry (it runs one fp32 path for both), so it is bounded here: cosine >= 1 - 1e-5 per row, max |diff| <= 1 % of
+    the embedding scale -- two orders inside the 1e-3 bar both passes meet against the fp32 oracle."""
+    enc, P, cfg_o = make_encoder(BASE1, 22, "average", gpu)
+    enc.eval()
+    ids, mask = ragged_batch(4, 256, 23, 1024, [256, 130, 256, 77])
+    ids, mask = ids.to(gpu), mask.to(gpu)
+    with torch.no_grad():
+        a = enc(input_ids=ids, attention_mask=mask).cpu()
+    b = enc(input_ids=ids, attention_mask=mask)
+    assert b.requires_grad and not a.requires_grad
+    b = b.detach().cpu()
+    c = cos_rows(a, b)
+    assert float(c.min()) >= 1 - 1e-5, c
+    assert float((a - b).abs().max()) <= 1e-2 * float(b.abs().max())
+    ref = O.encoder_forward(P, ids.cpu(), mask.cpu(), cfg_o, "average", False)
+    assert float(cos_rows(a, ref).min()) >= 1 - 1e-3 and float(cos_rows(b, ref).min()) >= 1 - 1e-3

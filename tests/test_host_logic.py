@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(lib.LIB_PATH)
     for name in declared:
         getattr(raw, name)
-    assert L.czc_abi_version() == 5
+    assert L.czc_abi_version() == 6
 
 
 def test_argument_checks_fail_without_launching():
@@ -172,3 +172,20 @@ def test_dropout_stream_is_pinned_to_roles_and_resumable(tmp_path):
     ib = inbatch.InBatch(opt)
     ib.set_dropout_position(3)
     assert ib.encoder.dropout_state() == {"salt": 0, "calls": 6}     # queries and keys: two training forwards per micro-step
+
+
+def test_stale_library_is_detected(monkeypatch):
+    """lib.load() compares the hash compiled into libczc.so with the sources beside it: a binary built
+    from other sources is rebuilt, and refused if the rebuild does not produce the expected hash."""
+    from czech_contriever_amd import build, lib
+    L = lib.load()
+    assert L.czc_source_hash().decode() == build.source_hash() == lib._embedded_hash(lib.LIB_PATH)
+    assert lib._fresh_or_rebuilt(lib.LIB_PATH) == lib.LIB_PATH
+    calls = []
+    monkeypatch.setattr(build, "source_hash", lambda extra=(): "0" * 40)      # "the sources changed"
+    monkeypatch.setattr(build, "build", lambda force=False, verbose=True: calls.append(1))   # a rebuild that changes nothing
+    with pytest.raises(RuntimeError, match="stale"):
+        lib._fresh_or_rebuilt(lib.LIB_PATH)
+    assert calls == [1]
+    monkeypatch.setenv("CZC_SKIP_HASH_CHECK", "1")
+    assert lib._fresh_or_rebuilt(lib.LIB_PATH) == lib.LIB_PATH

@@ -100,6 +100,32 @@ def per_kernel(dirname, counter, scale):
                 out[re.sub(r"\(.*", "", r["Kernel_Name"])].append(float(r["Counter_Value"]) * scale * 1024 / 1e6)
     return out
 F, W = per_kernel("pmc_fetch", "FETCH_SIZE", 2.0), per_kernel("pmc_write", "WRITE_SIZE", 1.0)
+
+
+def bench_ops_of(kernel):
+    """bench.py's operation names (czc_prof: "gemm a<al> b<bl> epi<e> MxNxK[ splitk][ (two products)]") that launch this
+    kernel template in the headline step -- the template's <AL, BL, EPI, Cfg, PP, ANT> against gemm_dispatch's choices
+    (csrc/gemm_bf16.hip: ANT = streaming A rows for K >= 1536 and N <= 1024; PP = ping-pong K-loop for the long-K / wide-N
+    K-major products).  Several names = the figures are this kernel's average over those operations."""
+    import re
+    m = re.search(r"gemm_kernel<(\d), (\d), (\d+), .*?>, (true|false), (true|false)>", kernel)
+    if not m or not bench:
+        return ""
+    al, bl, epi, pp, ant = int(m.group(1)), int(m.group(2)), int(m.group(3)), m.group(4) == "true", m.group(5) == "true"
+    names = []
+    for k in (bench["roofline"].get("kernels_all") or bench["roofline"].get("kernels") or []):
+        g = re.match(r"gemm a(\d) b(\d) epi(\d+) (\d+)x(\d+)x(\d+)", k["name"])
+        if not g or (int(g.group(1)), int(g.group(2)), int(g.group(3))) != (al, bl, epi):
+            continue
+        Kd, Nd = int(g.group(6)), int(g.group(5))
+        splitk = "splitk" in k["name"]
+        k_pp = al == 0 and bl == 0 and not splitk and (Kd >= 1536 or Nd >= 2304)
+        k_ant = k_pp and epi in (1, 4) and Kd >= 1536 and Nd <= 1024
+        if (k_ant, k_pp) == (ant, pp):
+            names.append(k["name"])
+    return "|".join(names)
+
+
 if F:
     steps = 3   # bench.py --steps 2 --warmup 1
     rows = []
@@ -110,10 +136,10 @@ if F:
     rows.sort(reverse=True)
     with open(os.path.join(prof, f"{tag}_traffic_kernels.csv"), "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["kernel", "launches_per_step", "fetch_MB_per_launch", "write_MB_per_launch", "GB_per_step", "distinct_fetch_MB"])
+        w.writerow(["kernel", "launches_per_step", "fetch_MB_per_launch", "write_MB_per_launch", "GB_per_step", "distinct_fetch_MB", "bench_ops"])
         for tot, k, n, fm, wm, dist in rows:
             if tot / steps < 1.0:
                 continue
-            w.writerow([k.strip(), round(n, 2), round(fm, 1), round(wm, 1), round(tot / steps / 1e3, 2), dist])
-        w.writerow([f"# total {sum(r[0] for r in rows) / steps / 1e3:.1f} GB per step; rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) over bench.py --steps 2 --warmup 1; FETCH_SIZE doubled (gfx950: 64 B counted per 128-B request); L2 misses, i.e. traffic from the Infinity Cache and HBM together; commit {commit}"])
+            w.writerow([k.strip(), round(n, 2), round(fm, 1), round(wm, 1), round(tot / steps / 1e3, 2), dist, bench_ops_of(k)])
+        w.writerow([f"# gemm_bf16.hip sha1 {gemm_sha}; total {sum(r[0] for r in rows) / steps / 1e3:.1f} GB per step; rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) over bench.py --steps 2 --warmup 1; FETCH_SIZE doubled (gfx950: 64 B counted per 128-B request); L2 misses, i.e. traffic from the Infinity Cache and HBM together; commit {commit}"])
 print("profiles written for commit", commit)
