@@ -222,6 +222,9 @@ __device__ __forceinline__ void swizzle_tile(int bid, int nwg, int tiles_m, int 
 // B panels and the shared A rows out of the 4 MiB the K-loop lives on), 2: nt
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_st;
 __device__ __forceinline__ void store16(u32x4_st v, __amdgpu_buffer_rsrc_t rc, unsigned off, int pol) {
+#ifdef CZC_EPI_NOSTORE   // diagnostic build: everything of the epilogue but the global stores (pol is a run-time value >= 0)
+  if (pol >= 0) return;
+#endif
   if (pol == 1) __builtin_amdgcn_raw_buffer_store_b128(v, rc, off, 0, 16);
   else if (pol == 2) __builtin_amdgcn_raw_buffer_store_b128(v, rc, off, 0, 2);
   else __builtin_amdgcn_raw_buffer_store_b128(v, rc, off, 0, 0);

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void head_mean_kernel(const float* __restrict_
   __syncthreads();
   if (threadIdx.x == 0) {
     stats[0] = (red[0] + red[1] + red[2] + red[3]) / (float)B;
-    stats[1] = 100.0f * (red[4] + red[5] + red[6] + red[7]) / (float)B;
+    stats[1] = ((red[4] + red[5] + red[6] + red[7]) / (float)B) * 100.0f;   // mean first, then percent: the reference's rounding
     stats[2] = 0.f; stats[3] = 0.f; stats[4] = 0.f; stats[5] = 0.f; stats[6] = 0.f; stats[7] = 0.f;
   }
 }
@@ -218,6 +218,135 @@ static HeadWs head_ws(int B, int C, int Kq) {
   return w;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// In-batch head (reference src/inbatch.py:71-75 + its autograd): scores = (q / T) . keys^T over the keys of ALL ranks
+// [N = W*B, C], cross-entropy with the positive of local query i at column label_offset + i, label smoothing, and the
+// gradients w.r.t. BOTH operands (queries and keys are differentiable there).  B <= a few hundred, N <= a few thousand:
+// 0.8 GFLOP forward, fp32 FMA throughout (what the reference's fp32 matmul gives), every sum in a fixed order.
+// ---------------------------------------------------------------------------------------------------------------------
+// 16 x 16 tile of scores per block: s[i][j] = invT * <q_i, k_j>
+__global__ __launch_bounds__(256) void inbatch_scores_kernel(const float* __restrict__ q, const float* __restrict__ k, int B, int N,
+                                                             int C, float invT, float* __restrict__ s) {
+  __shared__ float a[16][17], b[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+  float acc = 0.f;
+  for (int d0 = 0; d0 < C; d0 += 16) {
+    const int d = d0 + tx;
+    a[ty][tx] = (i0 + ty < B && d < C) ? q[(int64_t)(i0 + ty) * C + d] * invT : 0.f;   // (q / T) first, as the reference
+    b[ty][tx] = (j0 + ty < N && d < C) ? k[(int64_t)(j0 + ty) * C + d] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) acc = fmaf(a[ty][kk], b[tx][kk], acc);
+    __syncthreads();
+  }
+  if (i0 + ty < B && j0 + tx < N) s[(int64_t)(i0 + ty) * N + j0 + tx] = acc;
+}
+
+// one block per query row: log-sum-exp, loss, first arg-max, and the row of d loss / d scores written over the scores:
+// g_j = (p_j - (1 - ls) [j = y] - ls / N) / B      (F.cross_entropy with label_smoothing, mean over the batch)
+__global__ __launch_bounds__(256) void inbatch_row_kernel(float* __restrict__ s, int B, int N, int label_offset, float ls,
+                                                          float* __restrict__ rowloss, float* __restrict__ rowok) {
+  __shared__ float redf[4];
+  __shared__ int redi[4];
+  const int i = blockIdx.x, tid = threadIdx.x, y = label_offset + i;
+  float* row = s + (int64_t)i * N;
+  float mx = -INFINITY, sm = 0.f;
+  int am = 0x7fffffff;
+  for (int j = tid; j < N; j += 256) {
+    const float z = row[j];
+    if (z > mx) { mx = z; am = j; }     // first index of the maximum in this thread's strided run
+    sm += z;
+  }
+  // block maximum, then the smallest index that attains it (torch.argmax returns the first)
+  float wm = xor32_max(xor16_max(row_max16(mx)));
+  if ((tid & 63) == 0) redf[tid >> 6] = wm;
+  __syncthreads();
+  const float bm = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+  __syncthreads();
+  int cand = (mx == bm) ? am : 0x7fffffff;
+  for (int o = 32; o >= 1; o >>= 1) cand = min(cand, __shfl_xor(cand, o));
+  float se = 0.f;
+  for (int j = tid; j < N; j += 256) se += __expf(row[j] - bm);
+  se = wave_sum(se);
+  sm = wave_sum(sm);
+  if ((tid & 63) == 0) { redi[tid >> 6] = cand; redf[tid >> 6] = se; }
+  __syncthreads();
+  const int first = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+  const float sumexp = redf[0] + redf[1] + redf[2] + redf[3];
+  __syncthreads();
+  if ((tid & 63) == 0) redf[tid >> 6] = sm;
+  __syncthreads();
+  const float sumz = redf[0] + redf[1] + redf[2] + redf[3];
+  const float lse = bm + __logf(sumexp);
+  if (tid == 0) {
+    const float zy = row[y];
+    rowloss[i] = (1.0f - ls) * (lse - zy) + ls * (lse - sumz / (float)N);
+    rowok[i] = (first == y) ? 1.0f : 0.f;
+  }
+  __syncthreads();   // row[y] has been read before its owner overwrites it below
+  const float invB = 1.0f / (float)B, sm_eps = ls / (float)N;
+  for (int j = tid; j < N; j += 256) {
+    const float p = __expf(row[j] - lse);
+    row[j] = (p - (j == y ? 1.0f - ls : 0.f) - sm_eps) * invB;
+  }
+}
+
+// out_r = coef * sum_j w[r][j] x_j  (rows of `w` contiguous: d q_i = invT sum_j g[i][j] k_j), one block per output row
+__global__ __launch_bounds__(256) void inbatch_rowmix_kernel(const float* __restrict__ w, int ldw, const float* __restrict__ x, int n,
+                                                             int C, float coef, float* __restrict__ out) {
+  const int r = blockIdx.x, tid = threadIdx.x;
+  constexpr int MAXD = 16;                 // C <= 4096
+  float acc[MAXD];
+  const int nd = (C + 255) / 256;
+#pragma unroll
+  for (int u = 0; u < MAXD; ++u) acc[u] = 0.f;
+  for (int j = 0; j < n; ++j) {
+    const float wj = w[(int64_t)r * ldw + j];
+#pragma unroll
+    for (int u = 0; u < MAXD; ++u)
+      if (u < nd) { const int d = tid + 256 * u; if (d < C) acc[u] = fmaf(wj, x[(int64_t)j * C + d], acc[u]); }
+  }
+#pragma unroll
+  for (int u = 0; u < MAXD; ++u)
+    if (u < nd) { const int d = tid + 256 * u; if (d < C) out[(int64_t)r * C + d] = coef * acc[u]; }
+}
+// out_c = coef * sum_i w[i][c] x_i  (a COLUMN of `w`: d k_j = invT sum_i g[i][j] q_i), four output rows per block so that the
+// x rows are read once for the four
+__global__ __launch_bounds__(256) void inbatch_colmix_kernel(const float* __restrict__ w, int ldw, int ncols, const float* __restrict__ x,
+                                                             int n, int C, float coef, float* __restrict__ out) {
+  const int c0 = blockIdx.x * 4, tid = threadIdx.x;
+  constexpr int MAXD = 16;
+  const int nd = (C + 255) / 256;
+  float acc[4][MAXD];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int u = 0; u < MAXD; ++u) acc[r][u] = 0.f;
+  for (int i = 0; i < n; ++i) {
+    float wv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wv[r] = (c0 + r < ncols) ? w[(int64_t)i * ldw + c0 + r] : 0.f;
+#pragma unroll
+    for (int u = 0; u < MAXD; ++u)
+      if (u < nd) {
+        const int d = tid + 256 * u;
+        if (d < C) {
+          const float xv = x[(int64_t)i * C + d];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r][u] = fmaf(wv[r], xv, acc[r][u]);
+        }
+      }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (c0 + r < ncols)
+#pragma unroll
+      for (int u = 0; u < MAXD; ++u)
+        if (u < nd) { const int d = tid + 256 * u; if (d < C) out[(int64_t)(c0 + r) * C + d] = coef * acc[r][u]; }
+}
+
 }  // namespace czc
 
 using namespace czc;
@@ -312,6 +441,42 @@ extern "C" int czc_queue_import(const float* queue_f32, int dim, int queue_size,
   CZC_REQUIRE(dim > 0 && queue_size > 0, "czc_queue_import: dim=%d queue=%d", dim, queue_size);
   hipLaunchKernelGGL(queue_import_kernel, dim3(ceil_div(queue_size, 64), ceil_div(dim, 64)), dim3(256), 0,
                      (hipStream_t)stream, queue_f32, dim, queue_size, queue_bf16);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
+extern "C" int64_t czc_inbatch_workspace_floats(int batch, int n_keys) {
+  if (batch < 1 || n_keys < 1) return -1;
+  return (int64_t)batch * n_keys + 2 * (int64_t)batch;
+}
+
+extern "C" int czc_inbatch_head(const float* q, const float* keys, int batch, int n_keys, int dim, int label_offset,
+                                float temperature, float label_smoothing, float* workspace, int64_t workspace_floats,
+                                float* stats_out, float* dq, float* dkeys, czc_stream_t stream) {
+  CZC_REQUIRE(q && keys && workspace && stats_out, "czc_inbatch_head: null pointer");
+  CZC_REQUIRE(batch >= 2 && n_keys >= batch && dim >= 1 && dim <= 4096, "czc_inbatch_head: batch=%d (>= 2) n_keys=%d dim=%d (<= 4096)",
+              batch, n_keys, dim);
+  CZC_REQUIRE(label_offset >= 0 && label_offset + batch <= n_keys, "czc_inbatch_head: labels [%d, %d) outside the %d keys", label_offset,
+              label_offset + batch, n_keys);
+  CZC_REQUIRE(temperature > 0.f && label_smoothing >= 0.f && label_smoothing < 1.f, "czc_inbatch_head: temperature=%f label_smoothing=%f",
+              temperature, label_smoothing);
+  CZC_REQUIRE(workspace_floats >= czc_inbatch_workspace_floats(batch, n_keys), "czc_inbatch_head: workspace %lld < %lld floats",
+              (long long)workspace_floats, (long long)czc_inbatch_workspace_floats(batch, n_keys));
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope prof(st, "inbatch_head", 2.0 * batch * (double)n_keys * dim * ((dq ? 1 : 0) + (dkeys ? 1 : 0) + 1), 0.0);
+  const float invT = 1.0f / temperature;
+  float* s = workspace;
+  float* rowloss = s + (int64_t)batch * n_keys;
+  float* rowok = rowloss + batch;
+  hipLaunchKernelGGL(inbatch_scores_kernel, dim3(ceil_div(n_keys, 16), ceil_div(batch, 16)), dim3(256), 0, st, q, keys, batch, n_keys, dim,
+                     invT, s);
+  hipLaunchKernelGGL(inbatch_row_kernel, dim3(batch), dim3(256), 0, st, s, batch, n_keys, label_offset, label_smoothing, rowloss, rowok);
+  hipLaunchKernelGGL(head_mean_kernel, dim3(1), dim3(256), 0, st, rowloss, rowok, batch, stats_out);
+  // the reference's stdq / stdk: torch.std(qemb, dim=0).mean() and the same over THIS rank's keys (src/inbatch.py:84-85)
+  hipLaunchKernelGGL(colstd_kernel, dim3(ceil_div(dim, 64)), dim3(256), 0, st, q, batch, dim, stats_out + 2);
+  hipLaunchKernelGGL(colstd_kernel, dim3(ceil_div(dim, 64)), dim3(256), 0, st, keys + (int64_t)label_offset * dim, batch, dim, stats_out + 3);
+  if (dq) hipLaunchKernelGGL(inbatch_rowmix_kernel, dim3(batch), dim3(256), 0, st, s, n_keys, keys, n_keys, dim, invT, dq);
+  if (dkeys) hipLaunchKernelGGL(inbatch_colmix_kernel, dim3(ceil_div(n_keys, 4)), dim3(256), 0, st, s, n_keys, n_keys, q, batch, dim, invT, dkeys);
   CZC_LAUNCH_CHECK();
   return CZC_OK;
 }

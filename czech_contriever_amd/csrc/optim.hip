@@ -157,6 +157,51 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const int64_t i = (n4 << 2) + threadIdx.x; dst[i] = f2bf(src[i]); }
 }
 
+// weight_decay_from_init (reference src/moco.py:332-336): the penalty wd * sum((p - p0)^2) and its gradient 2 wd (p - p0),
+// each ONE pass over the flat arrays (the reference walks 197 tensors with three elementwise ops each)
+__global__ __launch_bounds__(256) void l2diff_partial_kernel(const float* __restrict__ p, const float* __restrict__ p0, int64_t n,
+                                                             float* partials) {
+  __shared__ float red[4];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float s = 0.f;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 d = __builtin_nontemporal_load((const f32x4*)p + i) - __builtin_nontemporal_load((const f32x4*)p0 + i);
+    s += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const int64_t i = (n4 << 2) + threadIdx.x; const float d = p[i] - p0[i]; s += d * d; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void l2diff_final_kernel(const float* __restrict__ partials, int np, float wd, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < np; i += 256) s += partials[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = wd * (red[0] + red[1] + red[2] + red[3]);
+}
+// g (+)= coef * scale[0] * (p - p0); scale = the upstream gradient of the penalty (a device scalar: no host round trip)
+__global__ __launch_bounds__(256) void l2diff_grad_kernel(const float* __restrict__ p, const float* __restrict__ p0, int64_t n,
+                                                          float coef, const float* __restrict__ scale, float* __restrict__ g,
+                                                          int accumulate) {
+  const float c = coef * (scale ? scale[0] : 1.0f);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 d = (__builtin_nontemporal_load((const f32x4*)p + i) - __builtin_nontemporal_load((const f32x4*)p0 + i)) * c;
+    ((f32x4*)g)[i] = accumulate ? ((const f32x4*)g)[i] + d : d;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    const float d = (p[i] - p0[i]) * c;
+    g[i] = accumulate ? g[i] + d : d;
+  }
+}
+
 static int flat_grid(int64_t n4) {
   int64_t b = (n4 + 255) / 256;
   if (b > 256 * 8) b = 256 * 8;   // 8 blocks per CU, grid-stride the rest
@@ -213,6 +258,29 @@ extern "C" int czc_sumsq(const float* g, int64_t n, float* partials, float* out,
   const int nb = flat_grid(n / 4);  // <= 2048 <= 4096 partials
   hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, n, partials);
   hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nb, out);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
+extern "C" int czc_l2_from_init_forward(const float* p, const float* p0, int64_t n, float weight_decay, float* partials,
+                                        float* out, czc_stream_t stream) {
+  CZC_REQUIRE(n > 0 && p && p0 && partials && out && ((uintptr_t)p % 16) == 0 && ((uintptr_t)p0 % 16) == 0,
+              "czc_l2_from_init_forward: bad arguments");
+  ProfScope prof((hipStream_t)stream, "l2_from_init_fwd", 0.0, 8.0 * n);
+  const int nb = flat_grid(n / 4);  // <= 2048 partials
+  hipLaunchKernelGGL(l2diff_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, p0, n, partials);
+  hipLaunchKernelGGL(l2diff_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nb, weight_decay, out);
+  CZC_LAUNCH_CHECK();
+  return CZC_OK;
+}
+
+extern "C" int czc_l2_from_init_backward(const float* p, const float* p0, int64_t n, float weight_decay, const float* upstream,
+                                         float* grads, int accumulate, czc_stream_t stream) {
+  CZC_REQUIRE(n > 0 && p && p0 && grads && ((uintptr_t)p % 16) == 0 && ((uintptr_t)p0 % 16) == 0 && ((uintptr_t)grads % 16) == 0,
+              "czc_l2_from_init_backward: bad arguments");
+  ProfScope prof((hipStream_t)stream, "l2_from_init_bwd", 0.0, (accumulate ? 16.0 : 12.0) * n);
+  hipLaunchKernelGGL(l2diff_grad_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, p0, n, 2.0f * weight_decay,
+                     upstream, grads, accumulate);
   CZC_LAUNCH_CHECK();
   return CZC_OK;
 }

@@ -447,3 +447,41 @@ class _InfoNCEFn(torch.autograd.Function):
 def infonce_loss(q, k, queue_bf16, temperature, label_smoothing, ws, stats_out):
     want = bool(torch.is_grad_enabled() and q.requires_grad)
     return _InfoNCEFn.apply(q, k, queue_bf16, temperature, label_smoothing, ws, stats_out, want)
+
+
+# ----------------------------------------------------------------------------------------------
+# In-batch head (autograd wrapper over czc_inbatch_head): SURVEY §8 row f4, reference src/inbatch.py:71-75
+# ----------------------------------------------------------------------------------------------
+class _InBatchHeadFn(torch.autograd.Function):
+    """loss = CE((q / T) . keys^T, label_offset + arange(B), label_smoothing); queries AND keys are differentiable.  Both
+    gradients come out of the same call as the loss (the scores are in the workspace then); backward scales them."""
+
+    @staticmethod
+    def forward(ctx, q, keys, label_offset, temperature, label_smoothing, ws, stats_out):
+        lib = L.load()
+        B, Cdim = q.shape
+        N = keys.shape[0]
+        qc, kc = q.contiguous(), keys.contiguous()
+        need_q, need_k = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dq = torch.empty_like(qc) if need_q else None
+        dk = torch.empty_like(kc) if need_k else None
+        L.check(lib.czc_inbatch_head(qc.data_ptr(), kc.data_ptr(), B, N, Cdim, int(label_offset), float(temperature),
+                                     float(label_smoothing), ws.data_ptr(), ws.numel(), stats_out.data_ptr(),
+                                     None if dq is None else dq.data_ptr(), None if dk is None else dk.data_ptr(), L.stream_ptr()))
+        ctx.save_for_backward(*[t for t in (dq, dk) if t is not None])
+        ctx.have = (need_q, need_k)
+        return stats_out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        saved = list(ctx.saved_tensors)
+        dq = saved.pop(0) * g if ctx.have[0] else None
+        dk = saved.pop(0) * g if ctx.have[1] else None
+        return dq, dk, None, None, None, None, None
+
+
+def inbatch_loss(q, keys, label_offset, temperature, label_smoothing, stats_out):
+    """-> loss (0-d); stats_out f32[8] on the device receives loss, accuracy %, stdq, stdk (include/czc.h)."""
+    n = int(L.load().czc_inbatch_workspace_floats(q.shape[0], keys.shape[0]))
+    ws = torch.empty(n, dtype=F32, device=q.device)
+    return _InBatchHeadFn.apply(q.to(F32), keys.to(F32), label_offset, temperature, label_smoothing, ws, stats_out)

@@ -50,6 +50,10 @@ SIGNATURES = {
     "czc_ema_update": (i32, [vp, vp, i64, f32, f32, vp, i64, vp]),
     "czc_adamw_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp, vp, i64, vp]),
     "czc_sumsq": (i32, [vp, i64, vp, vp, vp]),
+    "czc_l2_from_init_forward": (i32, [vp, vp, i64, f32, vp, vp, vp]),
+    "czc_l2_from_init_backward": (i32, [vp, vp, i64, f32, vp, vp, i32, vp]),
+    "czc_inbatch_workspace_floats": (i64, [i32, i32]),
+    "czc_inbatch_head": (i32, [vp, vp, i32, i32, i32, i32, f32, f32, vp, i64, vp, vp, vp, vp]),
     "czc_clip_coef": (i32, [vp, f32, f32, vp, vp]),
     "czc_clamp": (i32, [vp, i64, f32, f32, vp]),
     "czc_cast_bf16": (i32, [vp, vp, i64, vp]),

@@ -235,3 +235,28 @@ def distill_sim_loss(student, teacher):
     if student.shape[0] != teacher.shape[0]:
         raise ValueError(f"student {tuple(student.shape)} vs teacher {tuple(teacher.shape)}")
     return _DistillSimLoss.apply(student.contiguous().float(), teacher.detach().contiguous().float())
+
+
+def inbatch_head(q, keys, label_offset, temperature, label_smoothing=0.0, want_dq=True, want_dkeys=True):
+    """-> (stats f32[8]: loss, accuracy %, stdq, stdk; dq or None; dkeys or None)"""
+    B, C_ = q.shape
+    N = keys.shape[0]
+    ws = torch.empty(int(_l().czc_inbatch_workspace_floats(B, N)), dtype=F32, device=q.device)
+    stats = torch.empty(8, dtype=F32, device=q.device)
+    dq = torch.empty_like(q) if want_dq else None
+    dk = torch.empty_like(keys) if want_dkeys else None
+    L.check(_l().czc_inbatch_head(L.ptr(q, F32), L.ptr(keys, F32), B, N, C_, int(label_offset), float(temperature),
+                                  float(label_smoothing), L.ptr(ws), ws.numel(), L.ptr(stats), L.ptr(dq), L.ptr(dk), L.stream_ptr()))
+    return stats, dq, dk
+
+
+def l2_from_init(p, p0, weight_decay, grads=None, upstream=None, accumulate=True):
+    """-> penalty (0-d f32); with `grads`: grads (+)= 2 wd upstream (p - p0)"""
+    out = torch.empty(1, dtype=F32, device=p.device)
+    partials = torch.empty(4096, dtype=F32, device=p.device)
+    L.check(_l().czc_l2_from_init_forward(L.ptr(p, F32), L.ptr(p0, F32), p.numel(), float(weight_decay), L.ptr(partials), L.ptr(out),
+                                          L.stream_ptr()))
+    if grads is not None:
+        L.check(_l().czc_l2_from_init_backward(L.ptr(p, F32), L.ptr(p0, F32), p.numel(), float(weight_decay), L.ptr(upstream),
+                                               L.ptr(grads, F32), int(accumulate), L.stream_ptr()))
+    return out[0]

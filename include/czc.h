@@ -158,6 +158,17 @@ int czc_infonce_backward(const float* q, const float* k, const uint16_t* queue_b
                          const float* lse, float loss_scale,
                          void* workspace, int64_t workspace_bytes, float* dq, czc_stream_t stream);
 
+/* In-batch head — replaces src/inbatch.py:71-75 and its autograd: scores = (q / T) . keys^T over the keys
+ * of ALL ranks, keys f32 [n_keys, dim] in rank order; the positive of local query i is column label_offset + i
+ * (= rank * batch + i); F.cross_entropy with label smoothing, mean over the batch.  fp32 throughout, fixed summation
+ * order.  stats_out f32[8]: 0 loss, 1 accuracy %, 2 stdq, 3 stdk (std over THIS rank's keys, rows label_offset ..).
+ * dq f32 [batch, dim] and dkeys f32 [n_keys, dim] (either may be NULL) receive d loss / d q and d loss / d keys.
+ * workspace: czc_inbatch_workspace_floats(batch, n_keys) floats. */
+int64_t czc_inbatch_workspace_floats(int batch, int n_keys);
+int czc_inbatch_head(const float* q, const float* keys, int batch, int n_keys, int dim, int label_offset,
+                     float temperature, float label_smoothing, float* workspace, int64_t workspace_floats,
+                     float* stats_out, float* dq, float* dkeys, czc_stream_t stream);
+
 /* Ring-buffer enqueue — replaces MoCo._dequeue_and_enqueue after the gather (src/moco.py:277-287).
  * keys f32 [n, dim] (all ranks, rank order).  Writes rows [ptr, ptr+n) of queue_bf16 [K, dim] and,
  * when queue_f32 != NULL, the same keys into the reference-layout fp32 buffer queue_f32 [dim, K]
@@ -194,6 +205,14 @@ int czc_sumsq(const float* g, int64_t n, float* partials, float* out, czc_stream
 /* coef[0] = min(1, max_norm / (sqrt(sumsq[0]) * pre_scale + 1e-6))  (torch clip_grad_norm_) */
 int czc_clip_coef(const float* sumsq, float pre_scale, float max_norm, float* coef, czc_stream_t stream);
 int czc_clamp(float* g, int64_t n, float lo, float hi, czc_stream_t stream);
+
+/* --weight_decay_from_init (src/moco.py:332-336, 355-356): out[0] = weight_decay * sum((p - p0)^2) over the flat arrays
+ * (partials: >= 4096 floats of scratch; fixed summation order), and its gradient
+ * grads (+)= 2 * weight_decay * upstream[0] * (p - p0)   (upstream: device scalar, NULL = 1; accumulate 0 overwrites). */
+int czc_l2_from_init_forward(const float* p, const float* p0, int64_t n, float weight_decay, float* partials, float* out,
+                             czc_stream_t stream);
+int czc_l2_from_init_backward(const float* p, const float* p0, int64_t n, float weight_decay, const float* upstream,
+                              float* grads, int accumulate, czc_stream_t stream);
 
 /* dst_bf16[i] = bf16(src[i]) */
 int czc_cast_bf16(const float* src, uint16_t* dst, int64_t n, czc_stream_t stream);

@@ -10,13 +10,15 @@ FlatBertEncoder are pending when backward starts (engine.FlatBertEncoder._lease_
 activation workspaces apart) and both backwards accumulate into the same flat gradient array.  The keys of all
 ranks are concatenated in rank order by `dist_utils.gather` — an all-gather whose backward all-reduces the
 gradient and keeps this rank's slice (reference src/dist_utils.py:7-26) — so a query's positive sits at column
-rank * B + i (reference :73).  The [B, W*B] score matrix is a 0.8-GFLOP product: it stays a plain torch matmul
-on the device (no queue, nothing to fuse)."""
+rank * B + i (reference :73).  The [B, W*B] score product, the cross-entropy with label smoothing, the four stats
+and the gradients w.r.t. queries and keys are one libczc call (czc_inbatch_head, csrc/head.hip: fp32, fixed summation
+order)."""
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
 
+from czech_contriever_amd.engine import inbatch_loss
 from src import contriever, dist_utils
 from src.moco import MoCo, resolve_model_config
 
@@ -57,16 +59,13 @@ class InBatch(nn.Module):
         qemb = self.encoder(input_ids=q_tokens, attention_mask=q_mask, normalize=self.norm_query)
         kemb = self.encoder(input_ids=k_tokens, attention_mask=k_mask, normalize=self.norm_doc)
         all_keys = dist_utils.gather(kemb)
-        labels = torch.arange(bsz, dtype=torch.long, device=qemb.device) + dist_utils.get_rank() * len(kemb)
-        scores = (qemb / self.opt.temperature) @ all_keys.t()
-        loss = nn.functional.cross_entropy(scores, labels, label_smoothing=self.label_smoothing)
-
-        # the reference's four stats (:80-88); 0-d device tensors instead of .item() round trips
+        # scores = (qemb / T) @ all_keys^T, labels = rank * B + arange(B), F.cross_entropy(label_smoothing) and the four
+        # stats (:71-88) in one libczc call; the stats stay 0-d device tensors instead of .item() round trips
+        stats = torch.empty(8, dtype=torch.float32, device=qemb.device)
+        loss = inbatch_loss(qemb, all_keys, dist_utils.get_rank() * len(kemb), self.opt.temperature, self.label_smoothing, stats)
         prefix = stats_prefix + "/" if len(stats_prefix) > 0 else ""
-        with torch.no_grad():
-            hit = (scores.argmax(dim=-1) == labels).float().mean() * 100
-            iter_stats[f"{prefix}loss"] = (loss.detach(), bsz)
-            iter_stats[f"{prefix}accuracy"] = (hit, bsz)
-            iter_stats[f"{prefix}stdq"] = (torch.std(qemb, dim=0).mean(), bsz)
-            iter_stats[f"{prefix}stdk"] = (torch.std(kemb, dim=0).mean(), bsz)
+        iter_stats[f"{prefix}loss"] = (loss.detach(), bsz)
+        iter_stats[f"{prefix}accuracy"] = (stats[1], bsz)
+        iter_stats[f"{prefix}stdq"] = (stats[2], bsz)
+        iter_stats[f"{prefix}stdk"] = (stats[3], bsz)
         return loss, iter_stats

@@ -72,13 +72,18 @@ def resolve_model_config(model_id):
 
 
 class _L2FromInit(torch.autograd.Function):
-    """weight_decay * sum((p - p_init)^2) over the query encoder (src/moco.py:332-336), on the flat arrays."""
+    """weight_decay * sum((p - p_init)^2) over the query encoder (src/moco.py:332-336) and its gradient, each ONE pass of
+    libczc over the flat arrays (czc_l2_from_init_forward / _backward, csrc/optim.hip)."""
 
     @staticmethod
     def forward(ctx, anchor, enc, init_flat, wd):
         ctx.enc, ctx.init_flat, ctx.wd = enc, init_flat, wd
-        d = enc.flat_params - init_flat
-        return wd * (d * d).sum()
+        p = enc.flat_params
+        out = torch.empty(1, dtype=torch.float32, device=p.device)
+        partials = torch.empty(4096, dtype=torch.float32, device=p.device)
+        L.check(L.load().czc_l2_from_init_forward(p.data_ptr(), init_flat.data_ptr(), p.numel(), float(wd), partials.data_ptr(),
+                                                  out.data_ptr(), L.stream_ptr()))
+        return out[0]
 
     @staticmethod
     def backward(ctx, g):
@@ -88,12 +93,14 @@ class _L2FromInit(torch.autograd.Function):
         fresh = any(p.grad is None for p in enc._plist if p.requires_grad)
         grads = enc.flat_grads()
         if fresh:
-            grads.zero_()
             from czech_contriever_amd.engine import _numel
             for (name, shape, off), p in zip(enc._table, enc._plist):
                 if p.requires_grad:
                     p.grad = grads[off:off + _numel(shape)].view(shape)
-        grads.add_((enc.flat_params - ctx.init_flat) * (2.0 * ctx.wd) * g)
+        p = enc.flat_params
+        up = g.detach().reshape(1).to(torch.float32).contiguous()
+        L.check(L.load().czc_l2_from_init_backward(p.data_ptr(), ctx.init_flat.data_ptr(), p.numel(), float(ctx.wd), up.data_ptr(),
+                                                   grads.data_ptr(), 0 if fresh else 1, L.stream_ptr()))
         return torch.zeros_like(g).reshape(1), None, None, None
 
 

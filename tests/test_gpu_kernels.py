@@ -665,3 +665,52 @@ def test_gemm_output_store_policies_are_only_policies(ops):
             outs.append(torch.cat([x.reshape(-1) for x in o]) if isinstance(o, tuple) else o.reshape(-1))
         for o in outs[1:]:
             assert torch.equal(outs[0], o), epi
+
+
+# ------------------------------------------------------------------------------------------------
+# in-batch head (row f4) and the L2-from-init penalty (row a13) on libczc
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,N,C,off,T,ls", [(6, 6, 128, 0, 1.0, 0.0), (8, 24, 768, 8, 0.05, 0.1), (256, 2048, 768, 1792, 0.05, 0.0),
+                                            (33, 99, 320, 33, 0.5, 0.1)])
+def test_inbatch_head_matches_torch(ops, B, N, C, off, T, ls):
+    """czc_inbatch_head against the reference's arithmetic (src/inbatch.py:71-88) in fp32 torch on the device: loss, accuracy,
+    stdq, stdk, d loss / d q and d loss / d keys; world sizes 1 (N = B) to 8 (N = 8 B), this rank's block at `off`."""
+    q = rnd(B, C, seed=1, scale=0.4)
+    keys = rnd(N, C, seed=2, scale=0.4)
+    keys[off:off + B // 2] = q[:B // 2] * 0.9 + 0.02            # some easy positives: accuracy neither 0 nor 100
+    if B >= 8:
+        keys[3] = keys[off + 1]                                  # an exact tie with a positive's column: argmax takes the first
+    stats, dq, dk = ops.inbatch_head(q, keys, off, T, ls)
+    qv, kv = q.clone().requires_grad_(True), keys.clone().requires_grad_(True)
+    scores = (qv / T) @ kv.t()
+    labels = torch.arange(B, device=dev()) + off
+    loss = torch.nn.functional.cross_entropy(scores, labels, label_smoothing=ls)
+    loss.backward()
+    # a logit z carries an fp32 rounding error of a few ulp(z) whatever the summation order, and exp() turns it into that
+    # RELATIVE error of the probabilities: with un-normalised embeddings at T = 0.05 the logits reach ~2 500 (ulp 2.4e-4)
+    zerr = 16 * 1.2e-7 * float(scores.detach().abs().max())
+    report("inbatch loss", stats[0], loss.detach(), (2e-5 + zerr) * max(1.0, abs(float(loss.detach()))), 1e-5)
+    assert round(float(stats[1]) * B / 100) == int((scores.argmax(-1) == labels).sum())      # the same rows hit (ties: first index)
+    report("inbatch stdq", stats[2], torch.std(q, dim=0).mean(), 1e-6, 1e-5)
+    report("inbatch stdk", stats[3], torch.std(keys[off:off + B], dim=0).mean(), 1e-6, 1e-5)
+    report("inbatch dq", dq, qv.grad, (1e-5 + zerr) * float(qv.grad.abs().max()) + 1e-9, 1e-4)
+    report("inbatch dkeys", dk, kv.grad, (1e-5 + zerr) * float(kv.grad.abs().max()) + 1e-9, 1e-4)
+    again = ops.inbatch_head(q, keys, off, T, ls)
+    assert torch.equal(again[0][:2], stats[:2]) and torch.equal(again[1], dq) and torch.equal(again[2], dk)   # fixed summation order
+    only = ops.inbatch_head(q, keys, off, T, ls, want_dq=False, want_dkeys=False)
+    assert only[1] is None and only[2] is None and torch.equal(only[0][:2], stats[:2])
+
+
+def test_l2_from_init_kernels_match_torch(ops):
+    n = 1_000_003                                                # not a multiple of 4: the scalar tail
+    p, p0 = rnd(n, seed=1, scale=0.05), rnd(n, seed=2, scale=0.05)
+    wd = 0.01
+    g = rnd(n, seed=3, scale=0.01)
+    g0 = g.clone()
+    up = torch.tensor([0.5], device=dev())
+    pen = ops.l2_from_init(p, p0, wd, grads=g, upstream=up, accumulate=True)
+    ref = wd * ((p.double() - p0.double()) ** 2).sum()
+    assert abs(float(pen) - float(ref)) <= 1e-5 * float(ref)
+    report("l2 grad (accumulated)", g, g0 + 2 * wd * 0.5 * (p - p0), 1e-8, 1e-6)
+    ops.l2_from_init(p, p0, wd, grads=g, upstream=None, accumulate=False)
+    report("l2 grad (overwritten)", g, 2 * wd * (p - p0), 1e-8, 1e-6)
