@@ -457,6 +457,10 @@ def main():
         model = (moco.MoCo(opt) if args.objective == "moco" else inbatch.InBatch(opt)).to(device)
     model.train()
     optimizer, scheduler = utils.set_optim(opt, model)
+    if hasattr(model, "allow_ema_fold"):
+        # as train.py does on every step that no checkpoint follows: the next forward's momentum EMA rides in the AdamW pass
+        # (same arithmetic, bit for bit; CZC_EMA_FOLD=0 keeps the separate launch for A/B)
+        model.allow_ema_fold(os.environ.get("CZC_EMA_FOLD", "1") != "0")
     model = DataParallel(model, optimizer)
     batches = synthetic_batches(rank, args.batch, args.seq, 16, device, ragged=args.ragged)
     if rank == 0:

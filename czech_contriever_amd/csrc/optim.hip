@@ -62,21 +62,28 @@ struct AdamArgs {
   float one_minus_b1, one_minus_b2, step_size, inv_bc2_sqrt, grad_scale;
 };
 
-template <int V>   // as ema_kernel
+// EMA: the key encoder's momentum update of the NEXT forward in the same pass (pk = pk*em + p_new*eom while p_new is in
+// registers: the standalone EMA pass would read p and pk again and write pk -- 12 B per parameter saved).  The EMA's two
+// products and its add are rounded separately, exactly as ema_kernel does, so the fused pass is bit-identical to AdamW
+// followed by the EMA.
+struct EmaArgs { float* pk; bf16_t* pk_bf; float em, eom; };
+
+template <int V, bool EMA>   // V as ema_kernel
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, int64_t n4, int64_t n,
                                                     AdamArgs a, const float* __restrict__ clip_coef,
-                                                    bf16_t* __restrict__ p_bf, int64_t n_bf) {
+                                                    bf16_t* __restrict__ p_bf, int64_t n_bf, EmaArgs e) {
   constexpr bool NT = (V & 1) != 0;
   constexpr int U = (V & 2) ? 2 : 1;
   const float gs = a.grad_scale * (clip_coef ? clip_coef[0] : 1.0f);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += stride * U) {
-    f32x4 pp[U], gg[U], mm[U], vv[U];
+    f32x4 pp[U], gg[U], mm[U], vv[U], kk[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t i = i0 + u * stride;
       if (i < n4) {
+        if (EMA) kk[u] = NT ? __builtin_nontemporal_load((const f32x4*)e.pk + i) : ((const f32x4*)e.pk)[i];
         pp[u] = NT ? __builtin_nontemporal_load((const f32x4*)p + i) : ((const f32x4*)p)[i];
         gg[u] = (NT ? __builtin_nontemporal_load((const f32x4*)g + i) : ((const f32x4*)g)[i]) * gs;
         mm[u] = NT ? __builtin_nontemporal_load((const f32x4*)m + i) : ((const f32x4*)m)[i];
@@ -103,6 +110,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
           ((f32x4*)p)[i] = pp[u]; ((f32x4*)m)[i] = mm[u]; ((f32x4*)v)[i] = vv[u];
         }
         if (i * 4 + 3 < n_bf) st_bf4g(p_bf + i * 4, pp[u]);
+        if (EMA) {
+#pragma clang fp contract(off)  // two rounded products and a rounded add, as torch computes param_k * m + param_q * (1 - m)
+          f32x4 r;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const float p1 = kk[u][j] * e.em, p2 = pp[u][j] * e.eom; r[j] = p1 + p2; }
+          if (NT) __builtin_nontemporal_store(r, (f32x4*)e.pk + i); else ((f32x4*)e.pk)[i] = r;
+          if (i * 4 + 3 < n_bf) st_bf4g(e.pk_bf + i * 4, r);
+        }
       }
     }
   }
@@ -115,6 +130,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     x -= a.step_size * (m1 / (sqrtf(v1) * a.inv_bc2_sqrt + a.eps));
     p[i] = x; m[i] = m1; v[i] = v1;
     if (i < n_bf) p_bf[i] = f2bf(x);
+    if (EMA) {
+#pragma clang fp contract(off)
+      const float p1 = e.pk[i] * e.em, p2 = x * e.eom;
+      const float r = p1 + p2;
+      e.pk[i] = r;
+      if (i < n_bf) e.pk_bf[i] = f2bf(r);
+    }
   }
 }
 
@@ -227,14 +249,16 @@ extern "C" int czc_ema_update(float* pk, const float* pq, int64_t n, float m, fl
   return CZC_OK;
 }
 
-extern "C" int czc_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, int step, float grad_scale,
-                              const float* clip_coef_dev, uint16_t* p_bf16, int64_t n_bf16, czc_stream_t stream) {
+static int adamw_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, float grad_scale, const float* clip_coef_dev, uint16_t* p_bf16,
+                        int64_t n_bf16, float* pk, uint16_t* pk_bf16, float ema_m, float ema_om, czc_stream_t stream) {
   CZC_REQUIRE(n > 0 && step >= 1 && n_bf16 >= 0 && n_bf16 <= n && (n_bf16 % 4) == 0,
               "czc_adamw_step: n=%lld step=%d n_bf16=%lld", (long long)n, step, (long long)n_bf16);
   CZC_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
               "czc_adamw_step: arrays must be 16-byte aligned");
-  ProfScope prof((hipStream_t)stream, "adamw", 0.0, 28.0 * n + 2.0 * (p_bf16 ? n_bf16 : 0));
+  CZC_REQUIRE(!pk || (((uintptr_t)pk % 16) == 0 && pk != p && (n_bf16 == 0 || (pk_bf16 && p_bf16))),
+              "czc_adamw_ema_step: the key array must be 16-byte aligned, distinct from p, with its bf16 mirror");
+  ProfScope prof((hipStream_t)stream, pk ? "adamw+ema" : "adamw", 0.0, (pk ? 36.0 : 28.0) * n + (pk ? 4.0 : 2.0) * (p_bf16 ? n_bf16 : 0));
   AdamArgs a;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -247,10 +271,31 @@ extern "C" int czc_adamw_step(float* p, const float* g, float* m, float* v, int6
   a.grad_scale = grad_scale;
 // streaming loads / stores and two vectors per thread and iteration (eight loads in flight): 590-628 -> 549-553 us
   // in the step (either alone: 595)
-  hipLaunchKernelGGL(adamw_kernel<3>, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, n, a,
-                     clip_coef_dev, p_bf16, p_bf16 ? n_bf16 : 0);
+  EmaArgs e{pk, (bf16_t*)pk_bf16, ema_m, ema_om};
+  if (pk)
+    hipLaunchKernelGGL((adamw_kernel<3, true>), dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, n, a,
+                       clip_coef_dev, (bf16_t*)p_bf16, p_bf16 ? n_bf16 : 0, e);
+  else
+    hipLaunchKernelGGL((adamw_kernel<3, false>), dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, n, a,
+                       clip_coef_dev, (bf16_t*)p_bf16, p_bf16 ? n_bf16 : 0, e);
   CZC_LAUNCH_CHECK();
   return CZC_OK;
+}
+
+extern "C" int czc_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int step, float grad_scale,
+                              const float* clip_coef_dev, uint16_t* p_bf16, int64_t n_bf16, czc_stream_t stream) {
+  return adamw_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, clip_coef_dev, p_bf16, n_bf16,
+                      nullptr, nullptr, 0.f, 0.f, stream);
+}
+
+extern "C" int czc_adamw_ema_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                                  float beta2, float eps, float weight_decay, int step, float grad_scale,
+                                  const float* clip_coef_dev, uint16_t* p_bf16, int64_t n_bf16, float* pk,
+                                  uint16_t* pk_bf16, float ema_m, float ema_one_minus_m, czc_stream_t stream) {
+  CZC_REQUIRE(pk, "czc_adamw_ema_step: null key array");
+  return adamw_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, clip_coef_dev, p_bf16, n_bf16, pk,
+                      pk_bf16, ema_m, ema_one_minus_m, stream);
 }
 
 extern "C" int czc_sumsq(const float* g, int64_t n, float* partials, float* out, czc_stream_t stream) {

@@ -49,6 +49,7 @@ SIGNATURES = {
     "czc_queue_import": (i32, [vp, i32, i32, vp, vp]),
     "czc_ema_update": (i32, [vp, vp, i64, f32, f32, vp, i64, vp]),
     "czc_adamw_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp, vp, i64, vp]),
+    "czc_adamw_ema_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp, vp, i64, vp, vp, f32, f32, vp]),
     "czc_sumsq": (i32, [vp, i64, vp, vp, vp]),
     "czc_l2_from_init_forward": (i32, [vp, vp, i64, f32, vp, vp, vp]),
     "czc_l2_from_init_backward": (i32, [vp, vp, i64, f32, vp, vp, i32, vp]),

@@ -156,6 +156,13 @@ def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, clip
                                 L.stream_ptr()))
 
 
+def adamw_ema_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, pk, ema_m, grad_scale=1.0, clip_coef=None, p_bf16=None, n_bf16=0,
+                   pk_bf16=None):
+    L.check(_l().czc_adamw_ema_step(L.ptr(p, F32), L.ptr(g, F32), L.ptr(m, F32), L.ptr(v, F32), p.numel(), lr, beta1, beta2, eps, wd,
+                                    step, grad_scale, L.ptr(clip_coef), L.ptr(p_bf16), n_bf16, L.ptr(pk, F32), L.ptr(pk_bf16),
+                                    float(ema_m), float(1.0 - ema_m), L.stream_ptr()))
+
+
 def sumsq(g, partials, out):
     L.check(_l().czc_sumsq(L.ptr(g, F32), g.numel(), L.ptr(partials, F32), L.ptr(out, F32), L.stream_ptr()))
 

@@ -226,6 +226,9 @@ def train_student(opt, model, optimizer, scheduler, step, link, local_teacher, s
                 optimizer.clip_grad_value_(opt.max_grad_value)
             elif opt.max_grad_norm is not None:
                 optimizer.clip_grad_norm_(opt.max_grad_norm)
+        core = model.module if hasattr(model, "module") else model
+        nxt = step + 1       # (as train.py: no folded momentum update in front of a checkpoint or the end of the run)
+        core.allow_ema_fold(nxt < opt.total_steps and nxt % opt.eval_freq != 0 and nxt % opt.save_freq != 0)
         optimizer.step()
         scheduler.step()
         model.zero_grad()

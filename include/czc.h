@@ -200,6 +200,16 @@ int czc_adamw_step(float* p, const float* g, float* m, float* v, int64_t n,
                    float grad_scale, const float* clip_coef_dev,
                    uint16_t* p_bf16, int64_t n_bf16, czc_stream_t stream);
 
+/* AdamW and, in the same pass, the momentum EMA the NEXT forward would start with (src/moco.py:314 applies it before every
+ * key forward): pk = pk*ema_m + p_new*ema_one_minus_m while p_new is in registers, plus the key mirror pk_bf16 over the
+ * same n_bf16 elements.  Bit-identical to czc_adamw_step followed by czc_ema_update; 12 bytes per parameter less traffic
+ * and one launch fewer.  The caller then skips that forward's czc_ema_update (src/moco.MoCo: `_ema_prefolded`). */
+int czc_adamw_ema_step(float* p, const float* g, float* m, float* v, int64_t n,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                       float grad_scale, const float* clip_coef_dev,
+                       uint16_t* p_bf16, int64_t n_bf16, float* pk, uint16_t* pk_bf16, float ema_m,
+                       float ema_one_minus_m, czc_stream_t stream);
+
 /* sum of squares of g[0..n) -> out[0] (f32, device); out2 partial workspace of >= 4096 floats */
 int czc_sumsq(const float* g, int64_t n, float* partials, float* out, czc_stream_t stream);
 /* coef[0] = min(1, max_norm / (sqrt(sumsq[0]) * pre_scale + 1e-6))  (torch clip_grad_norm_) */

@@ -124,6 +124,11 @@ class MoCo(nn.Module):
         #  makes every per-kernel figure -- hipEvent probes, rocprofv3 -- read high)
         self.key_overlap = os.environ.get("CZC_KEY_OVERLAP", "0") == "1"
         self._key_stream = None
+        # The momentum EMA of the NEXT forward applied inside the optimizer's pass (FusedAdamW.attach_ema): the training
+        # loop switches it on for steps after which only the next training forward reads the key encoder (a checkpoint
+        # written in between would hold key weights one EMA ahead of the reference's; utils.save refuses that).
+        self.ema_fold = False
+        self._ema_prefolded = None
 
         retriever, tokenizer = self._load_retriever(opt.retriever_model_id, pooling=opt.pooling,
                                                     random_init=opt.random_init)
@@ -202,10 +207,19 @@ class MoCo(nn.Module):
             self._queue_version = q._version
         return self._queue_bf16
 
+    def allow_ema_fold(self, ok: bool):
+        """train.py / distill.py / bench.py, before optimizer.step(): True when nothing but the next training forward will
+        look at the key encoder after this step (no checkpoint, not the last step)."""
+        self.ema_fold = bool(ok)
+
     @torch.no_grad()
     def _momentum_update_key_encoder(self):
         """param_k = param_k * m + param_q * (1 - m) for every parameter: one launch (reference :260-269)."""
         ek, eq = self.encoder_k, self.encoder_q
+        if self._ema_prefolded is not None:
+            stamp, self._ema_prefolded = self._ema_prefolded, None
+            if stamp == (eq._write_stamp(), ek._write_stamp()):
+                return      # the optimizer's pass already applied THIS forward's EMA (czc_adamw_ema_step), bit for bit
         mirror = ek.mirror()
         L.check(L.load().czc_ema_update(ek.flat_params.data_ptr(), eq.flat_params.data_ptr(), ek.flat_params.numel(),
                                         float(self.momentum), float(1.0 - self.momentum), mirror.data_ptr(),

@@ -75,6 +75,11 @@ def save(model, optimizer, scheduler, step, opt, dir_path, name):
     root = os.path.join(dir_path, "checkpoint")
     target = os.path.join(root, name)
     os.makedirs(target, exist_ok=True)
+    if getattr(_unwrap(model), "_ema_prefolded", None) is not None:
+        # the optimizer's pass already applied the NEXT forward's momentum update to the key encoder (MoCo.allow_ema_fold):
+        # a checkpoint now would hold key weights one EMA ahead of the reference's and a resumed run would apply it twice
+        raise RuntimeError("utils.save after an optimizer step with the momentum update folded in: call "
+                           "model.allow_ema_fold(False) before the optimizer step that precedes a checkpoint")
     payload = {
         "step": step,
         "model": _unwrap(model).state_dict(),
@@ -144,6 +149,9 @@ def set_optim(opt, model):
     # torch's default decoupled decay of 0.01 applies on top of the L2-from-init penalty; kept as it is there
     wd = 0.01 if opt.weight_decay_from_init else opt.weight_decay
     optimizer = FusedAdamW(model, lr=opt.lr, betas=(opt.beta1, opt.beta2), eps=opt.eps, weight_decay=wd)
+    core = model.module if hasattr(model, "module") else model
+    if hasattr(core, "_momentum_update_key_encoder") and hasattr(core, "encoder_k"):
+        optimizer.attach_ema(core)      # MoCo / MoCoDistill: see FusedAdamW.attach_ema (off until the loop allows it per step)
     kinds = {"linear": WarmupLinearScheduler, "cosine": CosineScheduler}
     if opt.scheduler not in kinds:
         raise ValueError

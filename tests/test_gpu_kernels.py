@@ -667,6 +667,24 @@ def test_gemm_output_store_policies_are_only_policies(ops):
             assert torch.equal(outs[0], o), epi
 
 
+def test_adamw_with_folded_ema_is_bit_identical_to_the_two_passes(ops):
+    """czc_adamw_ema_step == czc_adamw_step followed by czc_ema_update, bit for bit (weights, moments, key weights, both bf16
+    mirrors), over several steps, n not a multiple of 4."""
+    n, nb, em = 1_000_003, 4096, 0.9995
+    pa, ka = rnd(n, seed=3), rnd(n, seed=4)
+    pb_, kb = pa.clone(), ka.clone()
+    ma, va, mb, vb = (torch.zeros(n, device=dev()) for _ in range(4))
+    mir = [torch.zeros(nb, dtype=BF16, device=dev()) for _ in range(4)]    # p / k mirrors of path a, then of path b
+    for step in range(1, 4):
+        g = rnd(n, seed=10 + step, scale=0.5)
+        ops.adamw_step(pa, g, ma, va, 1e-2, 0.9, 0.98, 1e-6, 0.01, step, 1.0, None, mir[0], nb)
+        ops.ema_update(ka, pa, em, mir[1], nb)
+        ops.adamw_ema_step(pb_, g, mb, vb, 1e-2, 0.9, 0.98, 1e-6, 0.01, step, kb, em, 1.0, None, mir[2], nb, mir[3])
+        for a, b, what in ((pa, pb_, "p"), (ka, kb, "k"), (ma, mb, "m"), (va, vb, "v"), (mir[0], mir[2], "p mirror"), (mir[1], mir[3], "k mirror")):
+            assert torch.equal(a, b), (step, what)
+    assert not torch.equal(ka, rnd(n, seed=4))
+
+
 # ------------------------------------------------------------------------------------------------
 # in-batch head (row f4) and the L2-from-init penalty (row a13) on libczc
 # ------------------------------------------------------------------------------------------------

@@ -397,3 +397,74 @@ def test_headline_config_micro_steps_match_oracle(tmp_path):
         assert abs(float(stats["train/stdk"][0]) - float(rs["stdk"])) < 1e-2 * max(1.0, float(rs["stdk"]))
         assert int(model.queue_ptr) == st.ptr == ((step + 1) * B) % K
     assert float((model.queue.cpu() - st.queue).abs().max()) < 3e-2 * float(st.queue.abs().max())
+
+
+def test_momentum_update_folded_into_the_optimizer_pass_changes_nothing(tmp_path):
+    """MoCo.allow_ema_fold(True): optimizer.step() applies the NEXT forward's momentum update (czc_adamw_ema_step) and that
+    forward skips its own.  From one state (weights, moments, gradients), the two orders -- step, then the forward's EMA;
+    and the folded step, then the forward's (skipped) EMA -- must leave both encoders, both bf16 mirrors and the moments bit
+    for bit the same, in one launch and in the matrix / tail pair of launches DataParallel uses; a checkpoint in between is
+    refused; a torch-side write to either encoder after the step cancels the skip."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from src import moco, utils
+    mdir = _cfg_dir(tmp_path)
+    dev = torch.device("cuda:0")
+    opt = types.SimpleNamespace(
+        queue_size=64, momentum=0.99, temperature=0.05, label_smoothing=0.1, norm_doc=True, norm_query=True,
+        moco_train_mode_encoder_k=False, weight_decay=0.01, weight_decay_from_init=False, retriever_model_id=mdir,
+        pooling="average", random_init=True, projection_size=128, optim="adamw", lr=1e-3, beta1=0.9, beta2=0.98,
+        eps=1e-6, warmup_steps=2, total_steps=10, lr_min_ratio=0.0, scheduler="linear")
+    torch.manual_seed(0)
+    model = moco.MoCo(opt).to(dev).train()
+    optimizer, scheduler = utils.set_optim(opt, model)
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(5, 500, (8, 32), generator=g).to(dev)
+    mask = torch.ones(8, 32, dtype=torch.bool, device=dev)
+    for _ in range(2):                                   # moments and a key encoder that differs from the query encoder
+        loss, _ = model(ids, mask, ids.flip(0), mask)
+        loss.backward(); optimizer.step(); model.zero_grad()
+    loss, _ = model(ids, mask, ids.flip(0), mask)
+    loss.backward()
+    eq, ek = model.encoder_q, model.encoder_k
+    m_, v_ = optimizer._moments(eq)
+    snap = [t.clone() for t in (eq.flat_params, ek.flat_params, m_, v_, eq.flat_grads())]
+    steps0 = optimizer._steps
+
+    def restore():
+        with torch.no_grad():
+            for dst, src in zip((eq.flat_params, ek.flat_params, m_, v_, eq.flat_grads()), snap):
+                dst.copy_(src)
+        eq.invalidate_mirror(); ek.invalidate_mirror()
+        optimizer._steps = steps0
+        model._ema_prefolded = None
+
+    def run(fold, split):
+        restore()
+        optimizer._pre_tail = [lambda: None] if split else []
+        model.allow_ema_fold(fold)
+        optimizer.step()
+        folded = model._ema_prefolded is not None
+        model._momentum_update_key_encoder()
+        torch.cuda.synchronize()
+        return [t.clone() for t in (eq.flat_params, ek.flat_params, m_, v_, eq.mirror(), ek.mirror())], folded
+    ref, f0 = run(False, False)
+    assert not f0
+    for split in (False, True):
+        got, f1 = run(True, split)
+        assert f1
+        for a, b, what in zip(ref, got, ("query weights", "key weights", "m", "v", "query mirror", "key mirror")):
+            assert torch.equal(a, b), (split, what)
+    assert not torch.equal(ref[1], snap[1])              # the key encoder did move
+    # a checkpoint between the folded step and the next forward is refused ...
+    restore(); model.allow_ema_fold(True); optimizer._pre_tail = []
+    optimizer.step()
+    with pytest.raises(RuntimeError, match="folded"):
+        utils.save(model, optimizer, scheduler, 3, opt, str(tmp_path), "bad")
+    # ... and a torch-side write to an encoder (load_state_dict) cancels the skip: the next forward applies its EMA itself
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)
+    before = ek.flat_params.clone()
+    model._momentum_update_key_encoder()
+    assert model._ema_prefolded is None and not torch.equal(ek.flat_params, before)
+    model.allow_ema_fold(False)

@@ -13,6 +13,8 @@ bf = torch.bfloat16
 M, H, I = 65536, 768, 3072
 NB = 3
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+if os.environ.get("CZC_GEMM_CFG"):   # czc_gemm_set_tile: 2 = 128x128 tiles at two workgroups per CU, +16 one workgroup per tile, ...
+    L.check(lib.czc_gemm_set_tile(int(os.environ["CZC_GEMM_CFG"])))
 def r(*s): return [(torch.randn(*s, device=dev) * 0.5).to(bf) for _ in range(NB)]
 def e(*s): return [torch.empty(*s, dtype=bf, device=dev) for _ in range(NB)]
 X, XI = r(M, H), r(M, I)

@@ -148,6 +148,11 @@ def train(opt, model, optimizer, scheduler, step):
             elif opt.max_grad_norm is not None:
                 optimizer.clip_grad_norm_(opt.max_grad_norm)
 
+        # the next forward's momentum update rides in the optimizer's pass unless a checkpoint is written first (MoCo.allow_ema_fold)
+        core = model.module if hasattr(model, "module") else model
+        if hasattr(core, "allow_ema_fold"):
+            nxt = step + 1
+            core.allow_ema_fold(nxt < opt.total_steps and nxt % opt.eval_freq != 0 and nxt % opt.save_freq != 0)
         optimizer.step()
         scheduler.step()
         model.zero_grad()
