@@ -4,7 +4,7 @@ import csv, glob, hashlib, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, tag = sys.argv[1], sys.argv[2]
 prof = os.path.join(ROOT, "profiles")
-commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+commit = os.environ.get("CZC_COMMIT") or subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()   # (the GPU box has no .git: the caller passes the hash)
 with open(os.path.join(ROOT, "czech_contriever_amd", "csrc", "gemm_bf16.hip"), "rb") as f:
     gemm_sha = hashlib.sha1(f.read()).hexdigest()
 
