@@ -407,13 +407,14 @@ def train_encoder(rc, cfg, P, pooling):
     return enc
 
 
-def g_train_masks(rc, rm, ru):
+def g_train_masks(rc, rm, ru, ri):
     """g15: the reference in TRAINING mode (dropout on: train.py:246, src/moco.py:306-321) under dropout outcomes taken
     from the kernels' counter RNG (tests/dropout_ref.py restates it in numpy; the fixture stores seeds, not masks):
       tiny_*   tiny encoder, ragged batch: embeddings + every parameter gradient of sum(emb * cot)
       base_*   bert-base-width layer, S 256 ragged: embeddings + subsampled gradients (as g12)
       split*_  key-encoder style no_grad pass whose last layer ran in two batch ranges (czc_encoder_forward split_batch)
-      moco_*   3 MoCo micro-steps with BOTH encoders in train mode (query seeds salt 0, key seeds salt 1)"""
+      moco_*   3 MoCo micro-steps with BOTH encoders in train mode (query seeds salt 0, key seeds salt 1)
+      inb_*    the in-batch objective's forward / backward in train mode (one encoder, two training forwards)"""
     from tests import dropout_ref as D
     out = {}
     # ---- tiny encoder
@@ -509,6 +510,27 @@ def g_train_masks(rc, rm, ru):
                moco_queue_final=m.queue,
                moco_wq_probe=m.encoder_q.state_dict()["encoder.layer.1.output.dense.weight"][::7, ::5],
                moco_wk_probe=m.encoder_k.state_dict()["encoder.layer.1.output.dense.weight"][::7, ::5])
+    # ---- the in-batch objective (src/inbatch.py:59-90), train mode: ONE encoder embeds queries, then keys -- two training
+    #      forwards, i.e. two consecutive positions of its dropout stream (salt 0, calls 1 and 2)
+    cfg = O.BertShape(**TINY)
+    P = O.make_params(cfg, 31)
+    q_ids, q_mask = ragged_batch(6, 24, 32, cfg.vocab_size, [24, 17, 5, 9, 24, 12])
+    k_ids, k_mask = ragged_batch(6, 20, 33, cfg.vocab_size, [20, 11, 7, 20, 3, 16])
+    inb_seed = 5151
+    enc = train_encoder(rc, cfg, P, "average")
+    opt_ns = argparse.Namespace(norm_doc=True, norm_query=True, label_smoothing=0.1, temperature=0.05)
+    m_in = ri.InBatch(opt_ns, retriever=enc, tokenizer=object())
+    m_in.train()
+    qm = D.encoder_scales(D.engine_seed(inb_seed, 1, 0), cfg, 6, 24)
+    km = D.encoder_scales(D.engine_seed(inb_seed, 2, 0), cfg, 6, 20)
+    with GivenDropout(scales_in_call_order(qm, cfg) + scales_in_call_order(km, cfg)):
+        loss, stats = m_in(q_tokens=q_ids, q_mask=q_mask, k_tokens=k_ids, k_mask=k_mask, stats_prefix="train", iter_stats={})
+    loss.backward()
+    out.update(inb_q_ids=q_ids, inb_q_mask=q_mask, inb_k_ids=k_ids, inb_k_mask=k_mask, inb_init_seed=inb_seed, inb_loss=loss.detach(),
+               inb_stats=np.array([float(stats["train/loss"][0]), float(stats["train/accuracy"][0]),
+                                   float(stats["train/stdq"][0]), float(stats["train/stdk"][0])]))
+    for n, p_ in enc.named_parameters():
+        out[f"inb_grad::{n}"] = p_.grad
     save("g15_train_masks.npz", **out)
 
 
@@ -535,7 +557,7 @@ def main():
         "g10": lambda: g_inbatch(rc, ri),
         "g12": lambda: g_base_grads(rc),
         "g13": lambda: g_distill(),
-        "g15": lambda: g_train_masks(rc, rm, ru),
+        "g15": lambda: g_train_masks(rc, rm, ru, ri),
     }
     for k, fn in jobs.items():
         if a.only and k not in a.only.split(","):

@@ -214,3 +214,117 @@ def test_training_mode_full_depth_vs_oracle(gpu):
                 for n, p in enc.named_parameters() if n.endswith("dense.weight") or n.endswith("query.weight")
                 or n.endswith("key.weight") or n.endswith("value.weight"))
     assert worst[0] >= 0.99, worst
+
+
+def test_training_mode_inbatch_vs_reference_golden(golden_dir, gpu, tmp_path):
+    """Row f4 with dropout on: the in-batch objective (one encoder, two training forwards: positions 1 and 2 of its dropout
+    stream) against the reference's InBatch.forward under the same outcomes (g15 inb_*): loss, stats, every gradient."""
+    from src import inbatch
+    g = load(golden_dir, "g15_train_masks.npz")
+    torch.manual_seed(int(g["inb_init_seed"]))
+    mdir = _write_cfg(tmp_path / "tiny", TINY)
+    opt = _moco_opt(mdir, norm_query=True, norm_doc=True, label_smoothing=0.1, temperature=0.05)
+    model = inbatch.InBatch(opt)
+    P = O.make_params(O.BertShape(**TINY), 31)
+    model.encoder.load_state_dict(P)
+    model = model.cuda()
+    model.train()
+    assert model.encoder.dropout_seed() == D.engine_seed(int(g["inb_init_seed"]), 1, 0)
+    loss, stats = model(t(g["inb_q_ids"]).to(gpu), t(g["inb_q_mask"]).to(gpu), t(g["inb_k_ids"]).to(gpu), t(g["inb_k_mask"]).to(gpu),
+                        stats_prefix="train", iter_stats={})
+    loss.backward()
+    ref = g["inb_stats"]
+    assert abs(float(loss) - float(ref[0])) < 1e-2 * max(1.0, abs(float(ref[0]))), (float(loss), float(ref[0]))
+    assert abs(float(stats["train/accuracy"][0]) - float(ref[1])) <= 100.0 / 6 + 1e-3     # B = 6: one near-tie row at most
+    assert abs(float(stats["train/stdq"][0]) - float(ref[2])) < 5e-3 and abs(float(stats["train/stdk"][0]) - float(ref[3])) < 5e-3
+    gmax = max(float(np.abs(g[f"inb_grad::{n}"]).max()) for n in P)
+    num = da = db = 0.0
+    for n, p in model.encoder.named_parameters():
+        r = t(g[f"inb_grad::{n}"]).double()
+        got = p.grad.detach().cpu().double()
+        scale = max(float(r.abs().max()), 0.01 * gmax)
+        assert float((got - r).abs().max()) <= 0.05 * scale, (n, float((got - r).abs().max()), scale)
+        num += float((got * r).sum()); da += float((got * got).sum()); db += float((r * r).sum())
+    assert num / (da ** 0.5 * db ** 0.5) > 0.998
+
+
+def test_training_mode_distill_student_step_vs_oracle(gpu, tmp_path):
+    """Row f2 with dropout on: the student's step of distill.py (MoCoDistill + the similarity-matrix loss against teacher
+    embeddings) against MoCoState.forward_backward(distill=..., q_masks, k_masks) under the same outcomes."""
+    import distill
+    from src import moco, utils
+    torch.manual_seed(777)
+    mdir = _write_cfg(tmp_path / "tiny", TINY)
+    opt = _moco_opt(mdir, norm_query=True, norm_doc=True, label_smoothing=0.0, temperature=0.05, distill_weight=0.5)
+    model = moco.MoCoDistill(opt)
+    cfg_o = O.BertShape(**TINY)
+    P = O.make_params(cfg_o, 71)
+    model.encoder_q.load_state_dict(P); model.encoder_k.load_state_dict(P)
+    queue = torch.nn.functional.normalize(O.det_uniform((128, 64), 72), dim=0)
+    with torch.no_grad():
+        model.queue.copy_(queue)
+    model = model.cuda().train()
+    st = O.MoCoState(cfg_o, P, queue, momentum=0.99, temperature=0.05, norm_query=True, norm_doc=True)
+    B, S = 8, 24
+    qt, qm = ragged_batch(B, S, 7300, 512, [S, 17, 3, 24, 9, 24, 12, 20])
+    kt, km = ragged_batch(B, S, 7400, 512, [20, S, 5, 11, 24, 7, 24, 16])
+    teacher = O.det_uniform((B, 48), 99)
+    sq, sk = model.encoder_q.dropout_seed(), model.encoder_k.dropout_seed()
+    loss, q_emb, _ = model(qt.to(gpu), qm.to(gpu), kt.to(gpu), km.to(gpu), process_group=None, stats_prefix="train", iter_stats={})
+    aux = distill.distill_loss(q_emb, teacher.to(gpu))
+    (0.5 * loss + 0.5 * aux).backward()
+    lo, qo, ko, extra = st.forward_backward(qt, qm, kt, km, training=True, distill=(teacher, 0.5, distill.DISTILL_LOSS_MULTIPLIER),
+                                            q_masks=D.encoder_scales(sq, cfg_o, B, S), k_masks=D.encoder_scales(sk, cfg_o, B, S))
+    assert abs(float(loss) - float(lo)) < 1e-2 * max(1.0, abs(float(lo))), (float(loss), float(lo))
+    assert abs(float(aux) - float(extra["distill_loss"])) < 1e-2 * max(1.0, abs(float(extra["distill_loss"])))
+    assert float(cos_rows(q_emb.detach().cpu(), qo).min()) >= 1 - 1e-3
+    num = da = db = 0.0
+    for n, p in model.encoder_q.named_parameters():
+        a, b = p.grad.detach().cpu().double().reshape(-1), st.Pq[n].grad.double().reshape(-1)
+        num += float((a * b).sum()); da += float((a * a).sum()); db += float((b * b).sum())
+    assert num / (da ** 0.5 * db ** 0.5) > 0.995, num / (da ** 0.5 * db ** 0.5)
+
+
+def test_training_mode_config1_sized_steps_vs_oracle(gpu, tmp_path):
+    """BASELINE.json configs[0] at its stated sizes (bert-base-uncased shape, chunk_length 64, per_gpu_batch_size 4,
+    queue_size 512) in the mode train.py runs it -- dropout 0.1 on in both encoders: three micro-steps with AdamW against the
+    oracle stepping under the same dropout outcomes."""
+    from src import moco, utils
+    from tests.test_gpu_train import BERT_BASE_UNCASED
+    torch.manual_seed(2024)
+    mdir = str(tmp_path / "bbu"); os.makedirs(mdir)
+    import json
+    with open(os.path.join(mdir, "config.json"), "w") as f:
+        json.dump(BERT_BASE_UNCASED, f)
+    K = 512
+    opt = _moco_opt(mdir, queue_size=K, momentum=0.9995, temperature=0.05, projection_size=768, norm_query=True, norm_doc=True,
+                    lr=1e-4, warmup_steps=0, total_steps=100, lr_min_ratio=1.0)
+    model = moco.MoCo(opt)
+    cfg_o = O.BertShape(**BERT_BASE_UNCASED)
+    P = O.make_params(cfg_o, 93)
+    model.encoder_q.load_state_dict(P); model.encoder_k.load_state_dict(P)
+    queue = O.init_queue(768, K, 0)
+    with torch.no_grad():
+        model.queue.copy_(queue)
+    model = model.to(gpu).train()
+    optimizer, scheduler = utils.set_optim(opt, model)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    st = O.MoCoState(cfg_o, P, queue, momentum=0.9995, temperature=0.05, norm_query=True, norm_doc=True)
+    B, S = 4, 64
+    for step in range(3):
+        qt, qm = ragged_batch(B, S, 9700 + step, 30522, [64, 40, 9, 27])
+        kt, km = ragged_batch(B, S, 9800 + step, 30522, [33, 64, 64, 12])
+        sq, sk = model.encoder_q.dropout_seed(), model.encoder_k.dropout_seed()
+        loss, stats = model(qt.to(gpu), qm.to(gpu), kt.to(gpu), km.to(gpu), stats_prefix="train", iter_stats={})
+        loss.backward()
+        lo, qo, ko, rs = st.forward_backward(qt, qm, kt, km, training=True, q_masks=D.encoder_scales(sq, cfg_o, B, S),
+                                             k_masks=D.encoder_scales(sk, cfg_o, B, S))
+        g_dev = torch.cat([p.grad.reshape(-1) for p in model.encoder_q.parameters()]).cpu().double()
+        g_ref = torch.cat([st.Pq[n].grad.reshape(-1) for n, _ in O.param_names(cfg_o)]).double()
+        c = float(torch.nn.functional.cosine_similarity(g_dev, g_ref, dim=0))
+        assert abs(float(loss) - float(lo)) < 2e-2 * max(1.0, abs(float(lo))), (step, float(loss), float(lo))
+        assert c > 0.99, (step, c)
+        optimizer.step(); scheduler.step(); model.zero_grad()
+        st.optimizer_step(1e-4)
+        assert int(model.queue_ptr) == st.ptr
+    assert float(cos_rows(model.queue.cpu().t()[:12], st.queue.t()[:12]).min()) >= 1 - 1e-3

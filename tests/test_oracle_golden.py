@@ -299,3 +299,27 @@ def test_training_mode_moco_steps_match_reference_under_given_masks(golden_dir):
     assert torch.allclose(st.queue, t(g["moco_queue_final"]), atol=1e-4)
     assert torch.allclose(st.Pq["encoder.layer.1.output.dense.weight"].detach()[::7, ::5], t(g["moco_wq_probe"]), atol=1e-5)
     assert torch.allclose(st.Pk["encoder.layer.1.output.dense.weight"][::7, ::5], t(g["moco_wk_probe"]), atol=1e-6)
+
+
+def test_training_mode_inbatch_matches_reference_under_given_masks(golden_dir):
+    """Row f4 in train mode: the reference's InBatch.forward under given dropout outcomes (one encoder, the query pass at
+    position 1 of its stream and the key pass at position 2)."""
+    from tests import dropout_ref as D
+    g = load(golden_dir, "g15_train_masks.npz")
+    cfg = O.BertShape(**TINY)
+    P = {n: v.requires_grad_(True) for n, v in O.make_params(cfg, 31).items()}
+    s = int(g["inb_init_seed"])
+    q_ids, k_ids = t(g["inb_q_ids"]), t(g["inb_k_ids"])
+    q = O.encoder_forward(P, q_ids, t(g["inb_q_mask"]), cfg, "average", True, training=True,
+                          masks=D.encoder_scales(D.engine_seed(s, 1, 0), cfg, *q_ids.shape))
+    k = O.encoder_forward(P, k_ids, t(g["inb_k_mask"]), cfg, "average", True, training=True,
+                          masks=D.encoder_scales(D.engine_seed(s, 2, 0), cfg, *k_ids.shape))
+    loss, acc, _ = O.inbatch_loss(q, k, 0, k.shape[0], 0.05, 0.1)
+    loss.backward()
+    ref = g["inb_stats"]
+    assert abs(float(loss) - float(ref[0])) < 2e-5 * max(1.0, abs(float(ref[0])))
+    assert float(acc) == float(ref[1])
+    for n, p in P.items():
+        r = t(g[f"inb_grad::{n}"])
+        scale = max(1e-6, float(r.abs().max()))
+        assert float((p.grad - r).abs().max()) <= 5e-4 * scale + 1e-6, n
